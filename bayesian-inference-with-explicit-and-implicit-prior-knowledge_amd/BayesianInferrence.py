@@ -1,0 +1,48 @@
+"""Matrix-normal-inverse-Wishart algebra (mirror of reference src/BayesianInferrence.py:11-61).
+
+Setup-time functions take and return NumPy arrays, as the reference's drivers call them on host
+data (src/Toy_Example.py:38-43).  The per-Gibbs-iteration use inside PGAS.sample_params runs on
+torch tensors on the engine's device (see PGAS.py).
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.linalg as sla
+
+
+def _solve_spd(A, B):
+    return sla.cho_solve(sla.cho_factor(A, lower=True), B)
+
+
+def prior_mniw_2naturalPara(mean, col_cov, row_scale, df):
+    """(mean, col_cov, row_scale, df) -> (eta_0 (M,n), eta_1 (M,M), eta_2 (n,n), eta_3)  [BI:18-32]."""
+    mean = np.atleast_2d(np.asarray(mean, dtype=np.float64))
+    row_scale = np.atleast_2d(np.asarray(row_scale, dtype=np.float64))
+    col_cov = np.asarray(col_cov, dtype=np.float64)
+    n, M = mean.shape
+    sol = _solve_spd(col_cov, np.hstack([mean.T, np.eye(M)]))
+    eta_0, eta_1 = sol[:, :n], sol[:, n:]
+    return eta_0, eta_1, mean @ eta_0 + row_scale, df
+
+
+def prior_mniw_2naturalPara_inv(eta_0, eta_1, eta_2, eta_3):
+    """Inverse map [BI:35-45]."""
+    eta_0 = np.asarray(eta_0, dtype=np.float64)
+    eta_1 = np.asarray(eta_1, dtype=np.float64)
+    n = eta_0.shape[1]
+    sol = _solve_spd(eta_1, np.hstack([eta_0, np.eye(eta_1.shape[0])]))
+    mean = sol[:, :n].T
+    return np.atleast_2d(mean), sol[:, n:], np.atleast_2d(np.asarray(eta_2) - mean @ eta_0), eta_3
+
+
+def prior_mniw_mean(eta_0, eta_1):
+    """Posterior mean with symmetrised eta_1 [BI:48-50]."""
+    eta_1 = np.asarray(eta_1, dtype=np.float64)
+    return _solve_spd(0.5 * (eta_1 + eta_1.T), np.asarray(eta_0, dtype=np.float64)).T
+
+
+def prior_mniw_calcStatistics(y, basis):
+    """Per-sample sufficient statistics [BI:53-61]."""
+    y = np.atleast_1d(np.asarray(y, dtype=np.float64))
+    basis = np.atleast_1d(np.asarray(basis, dtype=np.float64))
+    return np.outer(basis, y), np.outer(basis, basis), np.outer(y, y), 1

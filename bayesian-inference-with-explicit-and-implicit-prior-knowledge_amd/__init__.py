@@ -1,0 +1,33 @@
+"""MI355X-native Particle-Gibbs-with-Ancestor-Sampling engine.
+
+Host-side mirror of the reference's call surface for its particle-filter hot path
+(reference src/PGAS.py, src/Filtering.py, src/BasisFunctions.py, src/BayesianInferrence.py) over
+hand-written HIP kernels in ``libpgas_hip.so`` (C ABI: include/pgas_hip.h).
+
+Import as ``pgas_amd`` (the shim pgas_amd.py at the repository root maps that name onto this
+directory, whose own name is not a Python identifier).
+"""
+from . import random  # noqa: F401
+from .BasisFunctions import generate_Hilbert_BasisFunction  # noqa: F401
+from .BayesianInferrence import (  # noqa: F401
+    prior_mniw_2naturalPara,
+    prior_mniw_2naturalPara_inv,
+    prior_mniw_calcStatistics,
+    prior_mniw_mean,
+)
+from .descriptors import BasisMap, GaussianLikelihood, HilbertBasis  # noqa: F401
+from .PGAS import PGAS, condSequentialMonteCarlo  # noqa: F401
+
+__all__ = [
+    "PGAS",
+    "condSequentialMonteCarlo",
+    "generate_Hilbert_BasisFunction",
+    "HilbertBasis",
+    "BasisMap",
+    "GaussianLikelihood",
+    "prior_mniw_2naturalPara",
+    "prior_mniw_2naturalPara_inv",
+    "prior_mniw_calcStatistics",
+    "prior_mniw_mean",
+    "random",
+]

@@ -1,0 +1,235 @@
+"""ctypes binding of libpgas_hip.so (C ABI: include/pgas_hip.h) and the Engine wrapper.
+
+There is no CPU fallback: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpgas_hip.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class PgasError(RuntimeError):
+    pass
+
+
+class _ModelDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("T", C.c_int32), ("nx", C.c_int32), ("ny", C.c_int32), ("nu", C.c_int32),
+        ("M", C.c_int32), ("D", C.c_int32),
+        ("idx", _ip), ("sel", _ip), ("alpha", _dp), ("beta", _dp), ("nrm", C.c_double),
+        ("H", _dp), ("LRinv", _dp), ("cR", C.c_double),
+        ("m0", _dp), ("L0", _dp), ("y", _dp), ("u", _dp),
+        ("device", C.c_int32), ("keep_logw_trace", C.c_int32),
+    ]
+
+
+EXPORTS = [
+    "pgas_create", "pgas_destroy", "pgas_last_error", "pgas_segment_size", "pgas_set_params", "pgas_basis_eval",
+    "pgas_aux_states", "pgas_init_state", "pgas_step", "pgas_sweep", "pgas_get_traces", "pgas_last_final_index",
+    "pgas_suffstats",
+]
+
+_lib = None
+
+
+def load():
+    """Load libpgas_hip.so; raises PgasError if it has not been built (python __graft_entry__.py)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PgasError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc, gfx950); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, i64 = C.c_void_p, C.c_uint64, C.c_int32, C.c_int64
+    L.pgas_create.restype = C.c_int
+    L.pgas_create.argtypes = [C.POINTER(_ModelDesc), C.POINTER(vp)]
+    L.pgas_destroy.restype = None
+    L.pgas_destroy.argtypes = [vp]
+    L.pgas_last_error.restype = C.c_char_p
+    L.pgas_last_error.argtypes = [vp]
+    L.pgas_segment_size.restype = i32
+    L.pgas_set_params.restype = C.c_int
+    L.pgas_set_params.argtypes = [vp, vp, _dp, _dp, C.c_double, vp]
+    L.pgas_basis_eval.restype = C.c_int
+    L.pgas_basis_eval.argtypes = [vp, vp, i64, i32, vp, vp]
+    L.pgas_aux_states.restype = C.c_int
+    L.pgas_aux_states.argtypes = [vp, vp, i32, vp, vp]
+    L.pgas_init_state.restype = C.c_int
+    L.pgas_init_state.argtypes = [vp, u64, _dp, vp, vp]
+    L.pgas_step.restype = C.c_int
+    L.pgas_step.argtypes = [vp, i32, u64, vp, vp, _dp, vp, vp, vp, vp]
+    L.pgas_sweep.restype = C.c_int
+    L.pgas_sweep.argtypes = [vp, u64, vp, vp, vp]
+    L.pgas_get_traces.restype = C.c_int
+    L.pgas_get_traces.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.pgas_last_final_index.restype = C.c_int
+    L.pgas_last_final_index.argtypes = [vp, C.POINTER(i64), vp]
+    L.pgas_suffstats.restype = C.c_int
+    L.pgas_suffstats.argtypes = [vp, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _hp(a):
+    return a.ctypes.data_as(_dp)
+
+
+class _DevView:
+    """Minimal __cuda_array_interface__ carrier so torch can wrap library-owned device memory."""
+
+    def __init__(self, ptr, shape, typestr, owner):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+        self._owner = owner
+
+
+class Engine:
+    """One pgas_ctx: model tables on the device + launch methods on torch tensors."""
+
+    def __init__(self, N, observations, inputs, init_state_mean, init_state_cov, likelihood, basis_map, device=None, keep_logw_trace=False):
+        if not torch.cuda.is_available():
+            raise PgasError("no HIP device visible: the engine has no CPU path")
+        self.lib = load()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+        y = _f64(observations)
+        self.T = y.shape[0]
+        y = y.reshape(self.T, -1)
+        u = _f64(inputs).reshape(self.T, -1) if inputs is not None and np.size(inputs) else np.zeros((self.T, 0))
+        m0 = _f64(init_state_mean).reshape(-1)
+        self.N, self.nx, self.ny, self.nu = int(N), m0.shape[0], y.shape[1], u.shape[1]
+        if likelihood.nx != self.nx or likelihood.ny != self.ny:
+            raise ValueError("likelihood dimensions do not match the state / observation dimensions")
+        b = basis_map.basis
+        self.M, self.D = b.M, b.D
+        self._keep = dict(
+            idx=np.ascontiguousarray(b.indices, dtype=np.int32), sel=np.ascontiguousarray(basis_map.sel, dtype=np.int32),
+            alpha=_f64(basis_map.alpha), beta=_f64(basis_map.beta), H=_f64(likelihood.H), LRinv=_f64(likelihood.LRinv),
+            m0=m0, L0=_f64(np.linalg.cholesky(np.atleast_2d(_f64(init_state_cov)))), y=y, u=u if self.nu else np.zeros(1),
+        )
+        k = self._keep
+        d = _ModelDesc(
+            self.N, self.T, self.nx, self.ny, self.nu, self.M, self.D,
+            k["idx"].ctypes.data_as(_ip), k["sel"].ctypes.data_as(_ip), _hp(k["alpha"]), _hp(k["beta"]), b.norm,
+            _hp(k["H"]), _hp(k["LRinv"]), likelihood.cR, _hp(k["m0"]), _hp(k["L0"]), _hp(k["y"]),
+            _hp(k["u"]) if self.nu else None, self.device.index, 1 if keep_logw_trace else 0,
+        )
+        h = C.c_void_p()
+        rc = self.lib.pgas_create(C.byref(d), C.byref(h))
+        if rc != 0:
+            raise PgasError(f"pgas_create failed ({rc}): {self.lib.pgas_last_error(None).decode()}")
+        self._h = h
+        self.keep_logw_trace = bool(keep_logw_trace)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.pgas_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -------------------------------------------------------------- helpers
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise PgasError(f"{what} failed ({rc}): {self.lib.pgas_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, t, dtype=torch.float64, shape=None):
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+            t = torch.as_tensor(np.asarray(t) if not isinstance(t, torch.Tensor) else t, dtype=dtype, device=self.device).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            t = t.reshape(shape).contiguous()
+        return t
+
+    # -------------------------------------------------------------- calls
+    def set_params(self, coeff_mat, error_cov):
+        """coeff_mat (nx,M) tensor/array, error_cov (nx,nx)."""
+        A = self._dev(coeff_mat, shape=(self.nx, self.M))
+        S = np.atleast_2d(np.asarray(error_cov.detach().cpu() if isinstance(error_cov, torch.Tensor) else error_cov, dtype=np.float64))
+        LS = _f64(np.linalg.cholesky(S))
+        LSinv = _f64(np.linalg.inv(LS))
+        cS = float(-0.5 * self.nx * np.log(2 * np.pi) - np.sum(np.log(np.diag(LS))))
+        self._A = A  # keep alive until the pack kernel has run
+        self._chk(self.lib.pgas_set_params(self._h, A.data_ptr(), _hp(LS), _hp(LSinv), cS, self._stream()), "pgas_set_params")
+        return LS, LSinv, cS
+
+    def basis_eval(self, x, t):
+        x = self._dev(x).reshape(-1, self.nx)
+        phi = torch.empty((x.shape[0], self.M), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.pgas_basis_eval(self._h, x.data_ptr(), x.shape[0], t, phi.data_ptr(), self._stream()), "pgas_basis_eval")
+        return phi
+
+    def aux_states(self, x, t):
+        x = self._dev(x, shape=(self.N, self.nx))
+        aux = torch.empty_like(x)
+        self._chk(self.lib.pgas_aux_states(self._h, x.data_ptr(), t, aux.data_ptr(), self._stream()), "pgas_aux_states")
+        return aux
+
+    def init_state(self, seed, ref0):
+        x0 = torch.empty((self.N, self.nx), dtype=torch.float64, device=self.device)
+        r = _f64(ref0).reshape(self.nx)
+        self._chk(self.lib.pgas_init_state(self._h, seed, _hp(r), x0.data_ptr(), self._stream()), "pgas_init_state")
+        torch.cuda.current_stream(self.device).synchronize()  # r is host memory read asynchronously
+        return x0
+
+    def step(self, t, seed, log_weights, state, ref_t):
+        x = self._dev(state, shape=(self.N, self.nx))
+        lw = None if log_weights is None else self._dev(log_weights, shape=(self.N,))
+        r = _f64(ref_t.detach().cpu() if isinstance(ref_t, torch.Tensor) else ref_t).reshape(self.nx)
+        lw_new = torch.empty(self.N, dtype=torch.float64, device=self.device)
+        x_new = torch.empty((self.N, self.nx), dtype=torch.float64, device=self.device)
+        anc = torch.empty(self.N, dtype=torch.int32, device=self.device)
+        self._chk(
+            self.lib.pgas_step(self._h, t, seed, None if lw is None else lw.data_ptr(), x.data_ptr(), _hp(r), lw_new.data_ptr(),
+                               x_new.data_ptr(), anc.data_ptr(), self._stream()),
+            "pgas_step",
+        )
+        torch.cuda.current_stream(self.device).synchronize()
+        return lw_new, x_new, anc
+
+    def sweep(self, seed, ref_state):
+        ref = self._dev(ref_state, shape=(self.T, self.nx))
+        traj = torch.empty((self.T, self.nx), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.pgas_sweep(self._h, seed, ref.data_ptr(), traj.data_ptr(), self._stream()), "pgas_sweep")
+        self._ref_keepalive = ref
+        return traj
+
+    def traces(self):
+        """(state_trace (T,N,nx), ancestor_trace (T-1,N) int32, logw_last (N), logw_trace (T,N)|None) views."""
+        px, pa, pl, pt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        self._chk(self.lib.pgas_get_traces(self._h, C.byref(px), C.byref(pa), C.byref(pl), C.byref(pt)), "pgas_get_traces")
+        X = torch.as_tensor(_DevView(px.value, (self.T, self.N, self.nx), "<f8", self), device=self.device)
+        A = torch.as_tensor(_DevView(pa.value, (max(self.T - 1, 1), self.N), "<i4", self), device=self.device)
+        Lw = torch.as_tensor(_DevView(pl.value, (self.N,), "<f8", self), device=self.device)
+        Lt = torch.as_tensor(_DevView(pt.value, (self.T, self.N), "<f8", self), device=self.device) if pt.value else None
+        return X, A, Lw, Lt
+
+    def last_final_index(self):
+        v = C.c_int64()
+        self._chk(self.lib.pgas_last_final_index(self._h, C.byref(v), self._stream()), "pgas_last_final_index")
+        return int(v.value)
+
+    def suffstats(self, traj):
+        traj = self._dev(traj, shape=(self.T, self.nx))
+        T0 = torch.empty((self.M, self.nx), dtype=torch.float64, device=self.device)
+        T1 = torch.empty((self.M, self.M), dtype=torch.float64, device=self.device)
+        T2 = torch.empty((self.nx, self.nx), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.pgas_suffstats(self._h, traj.data_ptr(), T0.data_ptr(), T1.data_ptr(), T2.data_ptr(), self._stream()), "pgas_suffstats")
+        return T0, T1, T2, float(self.T - 1)

@@ -1,0 +1,439 @@
+// pgas_api.hip -- C ABI of libpgas_hip.so (include/pgas_hip.h) over the kernels of
+// pgas_kernels.hip.h.  Host side only: argument checking, device tables, launch sequencing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/pgas_hip.h"
+#include "pgas_kernels.hip.h"
+#include "pgas_suffstats.hip.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+typedef void (*front_fn)(DevModel, TransParams, int, uint64_t, const double*, const double*, const double*, double*, ScanBufs);
+typedef void (*fused_fn)(DevModel, TransParams, int, uint64_t, double, const double*, const double*, double*, ScanBufs, ScanBufs,
+                         int32_t*, double*);
+typedef void (*aux_fn)(DevModel, TransParams, int, const double*, double*);
+typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, int32_t*, double*);
+typedef void (*init_fn)(DevModel, uint64_t, const double*, const double*, double*);
+typedef void (*basis_fn)(DevModel, const int32_t*, const double*, int64_t, int, double*);
+
+struct Variant {
+    front_fn front;
+    fused_fn fused;
+    aux_fn aux;
+};
+
+template <int NX, int D, int JIN, int P>
+Variant make_variant() {
+    return Variant{k_front<NX, D, JIN, P>, k_fused<NX, D, JIN, P>, k_aux<NX, D, JIN, P>};
+}
+
+// (nx, D, padded innermost extent) -> kernel instantiation
+bool pick_variant(int nx, int D, int jin_needed, Variant* v, int* JP) {
+    if (D == 1) {
+        *JP = 1;
+        *v = nx == 1 ? make_variant<1, 1, 1, 4>() : make_variant<2, 1, 1, 4>();
+        return true;
+    }
+    const int jp = jin_needed <= 8 ? 8 : jin_needed <= 12 ? 12 : jin_needed <= 16 ? 16 : 0;
+    if (!jp) return false;
+    *JP = jp;
+    if (nx == 1) {
+        if (D == 2) *v = jp == 8 ? make_variant<1, 2, 8, 4>() : jp == 12 ? make_variant<1, 2, 12, 2>() : make_variant<1, 2, 16, 2>();
+        else *v = jp == 8 ? make_variant<1, 3, 8, 4>() : jp == 12 ? make_variant<1, 3, 12, 2>() : make_variant<1, 3, 16, 2>();
+    } else {
+        if (D == 2) *v = jp == 8 ? make_variant<2, 2, 8, 4>() : jp == 12 ? make_variant<2, 2, 12, 2>() : make_variant<2, 2, 16, 2>();
+        else *v = jp == 8 ? make_variant<2, 3, 8, 4>() : jp == 12 ? make_variant<2, 3, 12, 2>() : make_variant<2, 3, 16, 2>();
+    }
+    return true;
+}
+
+}  // namespace
+
+struct pgas_ctx {
+    DevModel md{};
+    int device = 0;
+    int keep_logw = 0;
+    Variant var{};
+    back_fn back = nullptr;
+    init_fn init = nullptr;
+    basis_fn basis = nullptr;
+    // device tables
+    double* d_y = nullptr;
+    double* d_u = nullptr;
+    int32_t* d_idx = nullptr;
+    int32_t* d_pos = nullptr;
+    double* d_m0L0 = nullptr;
+    double* d_ref = nullptr;   // nx doubles: ref_t of pgas_step / ref0 of pgas_init_state
+    double* d_G = nullptr;
+    int64_t gtotal = 0;        // doubles in d_G
+    TransParams tp{};
+    bool have_params = false;
+    ScanBufs sb[2]{};
+    // traces
+    double* x_trace = nullptr;
+    int32_t* anc_trace = nullptr;
+    double* logw_last = nullptr;
+    double* logw_trace = nullptr;
+    // suff-stat scratch
+    double* d_phi = nullptr;
+    std::string err;
+};
+
+#define FAIL(ctx, code, ...)                                  \
+    do {                                                      \
+        char buf_[512];                                       \
+        snprintf(buf_, sizeof buf_, __VA_ARGS__);             \
+        (ctx)->err = buf_;                                    \
+        return (code);                                        \
+    } while (0)
+
+#define HIPCHK(ctx, call)                                                                       \
+    do {                                                                                        \
+        hipError_t e_ = (call);                                                                 \
+        if (e_ != hipSuccess) FAIL(ctx, e_ == hipErrorOutOfMemory ? PGAS_E_NOMEM : PGAS_E_HIP,  \
+                                   "%s failed: %s", #call, hipGetErrorString(e_));              \
+    } while (0)
+
+#define KCHK(ctx, name)                                                                        \
+    do {                                                                                        \
+        hipError_t e_ = hipGetLastError();                                                      \
+        if (e_ != hipSuccess) FAIL(ctx, PGAS_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+    } while (0)
+
+static int alloc_scanbufs(pgas_ctx* c, ScanBufs* sb) {
+    const size_t np = (size_t)c->md.nseg * PGAS_SEG;
+    const int nsegp = (c->md.nseg + 63) / 64 * 64;
+    sb->nsegp = nsegp;
+    HIPCHK(c, hipMalloc(&sb->laux, np * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->c1, np * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc(&sb->c2, np * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc(&sb->segm, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->segs, 2 * nsegp * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc(&sb->excl, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->scale, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->cm, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->hdr, sizeof(UpperHdr)));
+    HIPCHK(c, hipMemset(sb->hdr, 0, sizeof(UpperHdr)));
+    return PGAS_OK;
+}
+static void free_scanbufs(ScanBufs* sb) {
+    hipFree(sb->laux); hipFree(sb->c1); hipFree(sb->c2); hipFree(sb->segm); hipFree(sb->segs);
+    hipFree(sb->excl); hipFree(sb->scale); hipFree(sb->cm); hipFree(sb->hdr);
+    *sb = ScanBufs{};
+}
+
+extern "C" {
+
+int32_t pgas_segment_size(void) { return PGAS_SEG; }
+
+const char* pgas_last_error(const pgas_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
+    if (!d->idx || !d->sel || !d->alpha || !d->beta || !d->H || !d->LRinv || !d->m0 || !d->L0 || !d->y)
+        FAIL(c, PGAS_E_ARG, "pgas_create: NULL table pointer");
+    if (d->N < 1 || d->T < 1 || d->M < 1) FAIL(c, PGAS_E_ARG, "pgas_create: N, T, M must be >= 1");
+    if (d->nx < 1 || d->nx > 2) FAIL(c, PGAS_E_ARG, "pgas_create: nx = %d not supported (compiled for nx in {1,2})", d->nx);
+    if (d->ny < 1 || d->ny > PGAS_MAX_NY) FAIL(c, PGAS_E_ARG, "pgas_create: ny = %d not supported (1..%d)", d->ny, PGAS_MAX_NY);
+    if (d->nu < 0 || d->nu > PGAS_MAX_NU) FAIL(c, PGAS_E_ARG, "pgas_create: nu = %d not supported (0..%d)", d->nu, PGAS_MAX_NU);
+    if (d->D < 1 || d->D > PGAS_MAX_D) FAIL(c, PGAS_E_ARG, "pgas_create: D = %d not supported (1..%d)", d->D, PGAS_MAX_D);
+    if (d->nu > 0 && !d->u) FAIL(c, PGAS_E_ARG, "pgas_create: nu > 0 but u == NULL");
+    const int64_t nseg64 = ((int64_t)d->N + PGAS_SEG - 1) / PGAS_SEG;
+    if (nseg64 > PG_MAX_NSEG) FAIL(c, PGAS_E_ARG, "pgas_create: N = %d exceeds %d particles per device", d->N, PG_MAX_NSEG * PGAS_SEG);
+
+    DevModel& md = c->md;
+    md.N = d->N; md.T = d->T; md.nx = d->nx; md.ny = d->ny; md.nu = d->nu; md.D = d->D; md.M = d->M;
+    md.nseg = (int)nseg64;
+    md.nrm = d->nrm; md.cR = d->cR;
+    for (int k = 0; k < d->D; ++k) {
+        if (d->sel[k] < 0 || d->sel[k] >= d->nx + d->nu) FAIL(c, PGAS_E_ARG, "pgas_create: sel[%d] = %d out of range", k, d->sel[k]);
+        md.sel[k] = d->sel[k]; md.alpha[k] = d->alpha[k]; md.beta[k] = d->beta[k];
+        // frequency progression of dimension k: j0, j0 + step, ...   (src/BasisFunctions.py:24-25)
+        int lo = d->idx[k], hi = d->idx[k], second = 0;
+        for (int m = 0; m < d->M; ++m) {
+            const int j = d->idx[m * d->D + k];
+            if (j < 1) FAIL(c, PGAS_E_ARG, "pgas_create: idx[%d][%d] = %d must be >= 1", m, k, j);
+            lo = j < lo ? j : lo; hi = j > hi ? j : hi;
+        }
+        for (int m = 0; m < d->M; ++m) {
+            const int j = d->idx[m * d->D + k];
+            if (j > lo && (second == 0 || j < second)) second = j;
+        }
+        md.j0[k] = lo; md.jstep[k] = second ? second - lo : 1;
+        for (int m = 0; m < d->M; ++m)
+            if ((d->idx[m * d->D + k] - lo) % md.jstep[k]) FAIL(c, PGAS_E_ARG, "pgas_create: idx column %d is not an arithmetic progression", k);
+        md.J[k] = (hi - lo) / md.jstep[k] + 1;
+        if (md.J[k] > PGAS_MAX_J && !(d->D == 1)) FAIL(c, PGAS_E_ARG, "pgas_create: %d frequencies in dimension %d (max %d)", md.J[k], k, PGAS_MAX_J);
+    }
+    for (int j = 0; j < d->ny; ++j)
+        for (int k = 0; k < d->nx; ++k) md.H[j * d->nx + k] = d->H[j * d->nx + k];
+    for (int j = 0; j < d->ny * d->ny; ++j) md.LRinv[j] = d->LRinv[j];
+    if (!pick_variant(d->nx, d->D, md.J[d->D - 1], &c->var, &md.JP))
+        FAIL(c, PGAS_E_ARG, "pgas_create: innermost basis dimension has %d frequencies (compiled up to 16)", md.J[d->D - 1]);
+    c->back = d->nx == 1 ? k_back<1> : k_back<2>;
+    c->init = d->nx == 1 ? k_init<1> : k_init<2>;
+    c->basis = d->nx == 1 ? k_basis_eval<1> : k_basis_eval<2>;
+    c->keep_logw = d->keep_logw_trace;
+
+    HIPCHK(c, hipSetDevice(d->device));
+    c->device = d->device;
+    // grid positions of the basis functions, innermost dimension padded to JP
+    std::vector<int32_t> pos(d->M);
+    int64_t gsize = 1;
+    for (int k = 0; k < d->D; ++k) gsize *= (k == d->D - 1 && d->D > 1) ? md.JP : md.J[k];
+    for (int m = 0; m < d->M; ++m) {
+        int64_t p = 0;
+        for (int k = 0; k < d->D; ++k) {
+            const int ext = (k == d->D - 1 && d->D > 1) ? md.JP : md.J[k];
+            p = p * ext + (d->idx[m * d->D + k] - md.j0[k]) / md.jstep[k];
+        }
+        pos[m] = (int32_t)p;
+    }
+    c->gtotal = gsize * d->nx;
+    HIPCHK(c, hipMalloc(&c->d_G, c->gtotal * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_pos, d->M * sizeof(int32_t)));
+    HIPCHK(c, hipMemcpy(c->d_pos, pos.data(), d->M * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_idx, (size_t)d->M * d->D * sizeof(int32_t)));
+    HIPCHK(c, hipMemcpy(c->d_idx, d->idx, (size_t)d->M * d->D * sizeof(int32_t), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_y, (size_t)d->T * d->ny * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_y, d->y, (size_t)d->T * d->ny * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_u, ((size_t)d->T * d->nu + 1) * sizeof(double)));
+    if (d->nu) HIPCHK(c, hipMemcpy(c->d_u, d->u, (size_t)d->T * d->nu * sizeof(double), hipMemcpyHostToDevice));
+    md.y = c->d_y; md.u = c->d_u;
+    std::vector<double> m0L0(d->nx + d->nx * d->nx);
+    for (int k = 0; k < d->nx; ++k) m0L0[k] = d->m0[k];
+    for (int k = 0; k < d->nx * d->nx; ++k) m0L0[d->nx + k] = d->L0[k];
+    HIPCHK(c, hipMalloc(&c->d_m0L0, m0L0.size() * sizeof(double)));
+    HIPCHK(c, hipMemcpy(c->d_m0L0, m0L0.data(), m0L0.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMalloc(&c->d_ref, 4 * sizeof(double)));
+    for (int i = 0; i < 2; ++i) {
+        int rc = alloc_scanbufs(c, &c->sb[i]);
+        if (rc) return rc;
+    }
+    const size_t ub = upper_smem_bytes(md.nseg);
+    if (ub > 48 * 1024)
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_upper), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ub));
+    return PGAS_OK;
+}
+
+int pgas_create(const pgas_model_desc* desc, pgas_ctx** out) {
+    if (!desc || !out) { g_create_error = "pgas_create: NULL argument"; return PGAS_E_ARG; }
+    pgas_ctx* c = new pgas_ctx();
+    int rc = create_impl(desc, c);
+    if (rc != PGAS_OK) {
+        g_create_error = c->err;
+        pgas_destroy(c);
+        *out = nullptr;
+        return rc;
+    }
+    *out = c;
+    return PGAS_OK;
+}
+
+void pgas_destroy(pgas_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
+    hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
+    hipFree(c->d_phi);
+    free_scanbufs(&c->sb[0]); free_scanbufs(&c->sb[1]);
+    delete c;
+}
+
+int pgas_set_params(pgas_ctx* c, const double* A_dev, const double* LS_host, const double* LSinv_host, double cS, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!A_dev || !LS_host || !LSinv_host) FAIL(c, PGAS_E_ARG, "pgas_set_params: NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int nx = c->md.nx;
+    for (int i = 0; i < 4; ++i) { c->tp.LS[i] = 0.0; c->tp.LSinv[i] = 0.0; }
+    for (int k = 0; k < nx; ++k)
+        for (int l = 0; l <= k; ++l) {
+            c->tp.LS[k * nx + l] = LS_host[k * nx + l];
+            c->tp.LSinv[k * nx + l] = LSinv_host[k * nx + l];
+        }
+    c->tp.cS = cS;
+    c->tp.G = c->d_G;
+    HIPCHK(c, hipMemsetAsync(c->d_G, 0, c->gtotal * sizeof(double), st));
+    const int64_t n = (int64_t)c->md.M * nx;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A_dev, c->d_pos, c->md.M, nx, c->md.nrm, c->d_G, c->gtotal);
+    KCHK(c, "k_pack");
+    c->have_params = true;
+    return PGAS_OK;
+}
+
+int pgas_basis_eval(pgas_ctx* c, const double* x_dev, int64_t np, int32_t t, double* phi_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!x_dev || !phi_dev || np < 0 || t < 0 || t >= c->md.T) FAIL(c, PGAS_E_ARG, "pgas_basis_eval: bad argument");
+    if (np == 0) return PGAS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(c->basis, dim3((unsigned)((np + PG_BLK - 1) / PG_BLK)), dim3(PG_BLK), 0, (hipStream_t)stream, c->md, c->d_idx, x_dev, np, t, phi_dev);
+    KCHK(c, "k_basis_eval");
+    return PGAS_OK;
+}
+
+int pgas_aux_states(pgas_ctx* c, const double* x_dev, int32_t t, double* aux_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!x_dev || !aux_dev || t < 0 || t >= c->md.T) FAIL(c, PGAS_E_ARG, "pgas_aux_states: bad argument");
+    if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_aux_states: call pgas_set_params first");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(c->var.aux, dim3(c->md.nseg), dim3(PG_BLK), 0, (hipStream_t)stream, c->md, c->tp, t, x_dev, aux_dev);
+    KCHK(c, "k_aux");
+    return PGAS_OK;
+}
+
+int pgas_init_state(pgas_ctx* c, uint64_t seed, const double* ref0_host, double* x0_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!ref0_host || !x0_dev) FAIL(c, PGAS_E_ARG, "pgas_init_state: NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(c, hipMemcpyAsync(c->d_ref, ref0_host, c->md.nx * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(c->init, dim3((c->md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, c->md, seed, c->d_m0L0, c->d_ref, x0_dev);
+    KCHK(c, "k_init");
+    return PGAS_OK;
+}
+
+static int launch_upper(pgas_ctx* c, const ScanBufs& sb, int nblocks, int search_block, double u, int final_mode, hipStream_t st) {
+    hipLaunchKernelGGL(k_upper, dim3(nblocks), dim3(PG_UPPER_THREADS), upper_smem_bytes(c->md.nseg), st, c->md.N, c->md.nseg, sb,
+                       search_block, u, final_mode);
+    KCHK(c, "k_upper");
+    return PGAS_OK;
+}
+
+int pgas_step(pgas_ctx* c, int32_t t, uint64_t seed, const double* logw_dev, const double* x_dev, const double* ref_t_host,
+              double* logw_new_dev, double* x_new_dev, int32_t* anc_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!x_dev || !ref_t_host || !logw_new_dev || !x_new_dev || !anc_dev) FAIL(c, PGAS_E_ARG, "pgas_step: NULL argument");
+    if (t < 0 || t >= c->md.T) FAIL(c, PGAS_E_ARG, "pgas_step: t = %d outside [0, %d)", t, c->md.T);
+    if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_step: call pgas_set_params first");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const DevModel& md = c->md;
+    HIPCHK(c, hipMemcpyAsync(c->d_ref, ref_t_host, md.nx * sizeof(double), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(c->var.front, dim3(md.nseg), dim3(PG_BLK), 0, st, md, c->tp, t, seed, x_dev, logw_dev, c->d_ref, x_new_dev, c->sb[0]);
+    KCHK(c, "k_front");
+    int rc = launch_upper(c, c->sb[0], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(c->back, dim3(md.nseg), dim3(PG_BLK), md.nseg * sizeof(double), st, md, t,
+                       pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), x_new_dev, c->sb[0], anc_dev, logw_new_dev);
+    KCHK(c, "k_back");
+    return PGAS_OK;
+}
+
+static int ensure_traces(pgas_ctx* c) {
+    if (c->x_trace) return PGAS_OK;
+    const DevModel& md = c->md;
+    const size_t row = (size_t)md.N * md.nx;
+    HIPCHK(c, hipMalloc(&c->x_trace, (size_t)md.T * row * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->anc_trace, (size_t)(md.T > 1 ? md.T - 1 : 1) * md.N * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&c->logw_last, (size_t)md.N * sizeof(double)));
+    if (c->keep_logw) {
+        HIPCHK(c, hipMalloc(&c->logw_trace, (size_t)md.T * md.N * sizeof(double)));
+        HIPCHK(c, hipMemset(c->logw_trace, 0, (size_t)md.T * md.N * sizeof(double)));
+    }
+    return PGAS_OK;
+}
+
+int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!ref_dev || !traj_dev) FAIL(c, PGAS_E_ARG, "pgas_sweep: NULL argument");
+    if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_sweep: call pgas_set_params first");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_traces(c);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const DevModel& md = c->md;
+    const int N = md.N, T = md.T, nx = md.nx;
+    const size_t row = (size_t)N * nx;
+    const dim3 grid(md.nseg), blk(PG_BLK);
+    const size_t cm_bytes = md.nseg * sizeof(double);
+
+    hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, c->x_trace);
+    KCHK(c, "k_init");
+    if (T == 1) {
+        HIPCHK(c, hipMemsetAsync(c->logw_last, 0, N * sizeof(double), st));
+    } else {
+        // t = 1: log-weights are zero (src/PGAS.py:163), nothing to resample yet
+        hipLaunchKernelGGL(c->var.front, grid, blk, 0, st, md, c->tp, 1, seed, c->x_trace, (const double*)nullptr, ref_dev + nx,
+                           c->x_trace + row, c->sb[1]);
+        KCHK(c, "k_front");
+        rc = launch_upper(c, c->sb[1], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, 1u), 0, st);
+        if (rc) return rc;
+        for (int t = 2; t < T; ++t) {
+            hipLaunchKernelGGL(c->var.fused, grid, blk, cm_bytes, st, md, c->tp, t, seed,
+                               pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)), c->x_trace + (size_t)(t - 1) * row,
+                               ref_dev + (size_t)t * nx, c->x_trace + (size_t)t * row, c->sb[(t - 1) & 1], c->sb[t & 1],
+                               c->anc_trace + (size_t)(t - 2) * N, c->logw_trace ? c->logw_trace + (size_t)(t - 1) * N : (double*)nullptr);
+            KCHK(c, "k_fused");
+            rc = launch_upper(c, c->sb[t & 1], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(c->back, grid, blk, cm_bytes, st, md, T - 1, pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(T - 1)),
+                           c->x_trace + (size_t)(T - 1) * row, c->sb[(T - 1) & 1], c->anc_trace + (size_t)(T - 2) * N, c->logw_last);
+        KCHK(c, "k_back");
+        if (c->logw_trace)
+            HIPCHK(c, hipMemcpyAsync(c->logw_trace + (size_t)(T - 1) * N, c->logw_last, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    // final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
+    ScanBufs& sf = c->sb[T & 1];
+    hipLaunchKernelGGL(k_segscan, grid, blk, 0, st, N, c->logw_last, sf);
+    KCHK(c, "k_segscan");
+    rc = launch_upper(c, sf, 1, 0, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), 1, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, st, N, T, nx, c->x_trace, c->anc_trace, sf.hdr, traj_dev);
+    KCHK(c, "k_backtrace");
+    return PGAS_OK;
+}
+
+int pgas_get_traces(pgas_ctx* c, double** x_trace, int32_t** anc_trace, double** logw_last, double** logw_trace) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->x_trace) FAIL(c, PGAS_E_STATE, "pgas_get_traces: no sweep has run");
+    if (x_trace) *x_trace = c->x_trace;
+    if (anc_trace) *anc_trace = c->anc_trace;
+    if (logw_last) *logw_last = c->logw_last;
+    if (logw_trace) *logw_trace = c->logw_trace;
+    return PGAS_OK;
+}
+
+int pgas_last_final_index(pgas_ctx* c, int64_t* idx, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!idx) FAIL(c, PGAS_E_ARG, "pgas_last_final_index: NULL argument");
+    if (!c->x_trace) FAIL(c, PGAS_E_STATE, "pgas_last_final_index: no sweep has run");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    UpperHdr h;
+    HIPCHK(c, hipMemcpy(&h, c->sb[c->md.T & 1].hdr, sizeof h, hipMemcpyDeviceToHost));
+    *idx = h.final_idx;
+    return PGAS_OK;
+}
+
+int pgas_suffstats(pgas_ctx* c, const double* traj_dev, double* T0_dev, double* T1_dev, double* T2_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!traj_dev || !T0_dev || !T1_dev || !T2_dev) FAIL(c, PGAS_E_ARG, "pgas_suffstats: NULL argument");
+    const DevModel& md = c->md;
+    if (md.T < 2) FAIL(c, PGAS_E_ARG, "pgas_suffstats: needs T >= 2");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int R = md.T - 1;                         // rows: t = 0..T-2   (traj[:-1], inputs[:-1]; Q3)
+    const int Mp = (md.M + 15) / 16 * 16;           // padded to the MFMA tile
+    const int Rp = (R + 3) / 4 * 4;
+    if (!c->d_phi) HIPCHK(c, hipMalloc(&c->d_phi, (size_t)Rp * Mp * sizeof(double)));
+    HIPCHK(c, hipMemsetAsync(c->d_phi, 0, (size_t)Rp * Mp * sizeof(double), st));
+    hipLaunchKernelGGL(md.nx == 1 ? k_traj_basis<1> : k_traj_basis<2>, dim3((R + 63) / 64), dim3(64), 0, st, md, c->d_idx, traj_dev, R, Mp, c->d_phi);
+    KCHK(c, "k_traj_basis");
+    const int tiles = Mp / 16;
+    hipLaunchKernelGGL(k_syrk_mfma, dim3(tiles, tiles), dim3(64), 0, st, c->d_phi, Rp, Mp, md.M, T1_dev);
+    KCHK(c, "k_syrk_mfma");
+    hipLaunchKernelGGL(k_t0t2, dim3((md.M + 63) / 64 + 1), dim3(64), 0, st, c->d_phi, traj_dev, R, Mp, md.M, md.nx, T0_dev, T2_dev);
+    KCHK(c, "k_t0t2");
+    return PGAS_OK;
+}
+
+}  // extern "C"

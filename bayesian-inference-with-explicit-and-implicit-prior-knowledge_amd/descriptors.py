@@ -1,0 +1,106 @@
+"""Declarative stand-ins for the Python callables the reference hands to its algorithms.
+
+The reference's ``basis_fcn(state, input)`` and ``likelihood_fcn(obs, state, input)`` are Python
+lambdas traced by JAX (src/PGAS.py:20-21).  A HIP kernel cannot trace a lambda, so the two families
+the reference instantiates are described by small tables (see include/pgas_hip.h).  The objects
+are still callable on the host, so code such as ``len(basis_fcn(m0, u0))`` (src/PGAS.py:41-43)
+keeps working.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class HilbertBasis:
+    """Hilbert-space GP basis on a box (reference src/BasisFunctions.py:8-80).
+
+    phi_m(x) = prod_d sqrt(1/L_d) sin(sqrt(eig_md) (x_d - center_d + L_d)),  sqrt(eig_md) = pi j_md / (2 L_d).
+    """
+
+    def __init__(self, indices, domain_boundary):
+        box = np.atleast_2d(np.asarray(domain_boundary, dtype=np.float64))
+        self.indices = np.ascontiguousarray(np.atleast_2d(indices), dtype=np.int32)  # (M, D) frequencies j
+        self.size = box[:, 1] - box[:, 0]
+        self.center = (box[:, 0] + box[:, 1]) / 2
+        self.L = self.size / 2
+        self.M, self.D = self.indices.shape
+        if self.D != box.shape[0]:
+            raise ValueError("index table and domain have different dimensions")
+
+    @property
+    def eigenvalues(self):
+        return (np.pi * self.indices / self.size) ** 2
+
+    @property
+    def norm(self):
+        return float(np.prod(np.sqrt(1.0 / self.L)))
+
+    def __call__(self, x):
+        """Host evaluation for one point x (D,) or scalar when D == 1 -> (M,)."""
+        xc = np.asarray(x, dtype=np.float64).reshape(-1)[: self.D] - self.center
+        ang = np.pi * self.indices * (xc + self.L) / self.size
+        return np.prod(np.sqrt(1.0 / self.L) * np.sin(ang), axis=1)
+
+    def on(self, sel, div=None):
+        """basis evaluated at concat(state, input)[sel] / div -- a ``basis_fcn(state, input)``."""
+        return BasisMap(self, sel, div)
+
+    def __len__(self):
+        return self.M
+
+
+class BasisMap:
+    """``basis_fcn(state, input) = basis(concat(state, input)[sel] / div)``.
+
+    Covers src/Toy_Example.py:146 (sel=[0]), src/SingleMassOscillator.py:151 (sel=[0,1]) and
+    src/EMPS.py:110-113 (sel=[0,1,2], div=[0.4,0.4,160]).
+    """
+
+    def __init__(self, basis: HilbertBasis, sel, div=None):
+        self.basis = basis
+        self.sel = np.ascontiguousarray(np.atleast_1d(sel), dtype=np.int32)
+        self.div = np.ones(basis.D) if div is None else np.asarray(div, dtype=np.float64).reshape(-1)
+        if self.sel.shape[0] != basis.D or self.div.shape[0] != basis.D:
+            raise ValueError("sel/div must have one entry per basis dimension")
+
+    def __call__(self, state, input=None):
+        v = np.atleast_1d(np.asarray(state, dtype=np.float64)).reshape(-1)
+        if input is not None and np.size(input):
+            v = np.concatenate([v, np.atleast_1d(np.asarray(input, dtype=np.float64)).reshape(-1)])
+        return self.basis(v[self.sel] / self.div)
+
+    # engine tables: r_d = v[sel_d] * alpha_d + beta_d
+    @property
+    def alpha(self):
+        return 1.0 / (self.div * self.basis.size)
+
+    @property
+    def beta(self):
+        return (self.basis.L - self.basis.center) / self.basis.size
+
+
+class GaussianLikelihood:
+    """``likelihood_fcn(obs, state, input) = log N(obs; H state, R)``
+    (src/Toy_Example.py:142-144, src/EMPS.py:250-252: mvn.logpdf(obs, mean=f_y(state), cov=R))."""
+
+    def __init__(self, H, R):
+        self.H = np.atleast_2d(np.asarray(H, dtype=np.float64))
+        self.R = np.atleast_2d(np.asarray(R, dtype=np.float64))
+        self.ny, self.nx = self.H.shape
+        if self.R.shape != (self.ny, self.ny):
+            raise ValueError("R must be (ny, ny)")
+        self.LR = np.linalg.cholesky(self.R)
+        self.LRinv = np.linalg.inv(self.LR)
+        self.cR = float(-0.5 * self.ny * np.log(2 * np.pi) - np.sum(np.log(np.diag(self.LR))))
+
+    @classmethod
+    def of_component(cls, index, nx, R):
+        """f_y(x) = x[index] (src/EMPS.py:197-198, src/SingleMassOscillator.py:47-48)."""
+        H = np.zeros((1, nx))
+        H[0, index] = 1.0
+        return cls(H, R)
+
+    def __call__(self, obs, state, input=None):
+        e = np.atleast_1d(np.asarray(obs, dtype=np.float64)) - self.H @ np.atleast_1d(np.asarray(state, dtype=np.float64))
+        w = self.LRinv @ e
+        return float(self.cR - 0.5 * w @ w)

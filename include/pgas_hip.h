@@ -1,0 +1,128 @@
+/*
+ * pgas_hip.h -- C ABI of libpgas_hip.so, the MI355X (gfx950) engine for the conditional-SMC /
+ * PGAS hot path of VolkmannB/bayesian-inference-with-explicit-and-implicit-prior-knowledge.
+ *
+ * The reference has no FFI: its boundary is the Python call surface of src/PGAS.py.  Each entry
+ * point below names the reference interface it stands under (paths relative to the reference
+ * root); INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no C++ types, no torch types; every function returns 0 on success or a negative
+ *     PGAS_E_* code, and pgas_last_error(ctx) gives the message.  No exceptions cross the ABI.
+ *   - "dev" pointers are device (HBM) pointers on ctx's device, "host" pointers are ordinary
+ *     host memory read during the call.  The caller owns every buffer it passes; the library
+ *     owns only the context (model tables, traces, scan scratch).
+ *   - all work is enqueued on the caller's stream (`stream` = hipStream_t, e.g.
+ *     torch.cuda.current_stream().cuda_stream); calls return without synchronising unless noted.
+ *   - one context per device; a context is not thread-safe, distinct contexts are independent.
+ *   - arithmetic is fp64 throughout (reference src/__init__.py:4) in the canonical order of
+ *     DESIGN.md section 4; ancestor indices are int32.
+ *   - particle arrays are row-major (N, nx) exactly as the reference's state_trace[t]
+ *     (src/PGAS.py:160-162).
+ */
+#ifndef PGAS_HIP_H
+#define PGAS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGAS_OK 0
+#define PGAS_E_ARG (-1)      /* bad argument / unsupported model shape */
+#define PGAS_E_HIP (-2)      /* a HIP runtime call failed */
+#define PGAS_E_STATE (-3)    /* call sequence error (e.g. sweep before set_params) */
+#define PGAS_E_NOMEM (-4)    /* device allocation failed */
+
+typedef struct pgas_ctx pgas_ctx;
+
+/*
+ * Declarative model description.  The reference passes Python callables that JAX traces
+ * (basis_fcn, likelihood_fcn: src/PGAS.py:20-21,31-32); a HIP kernel cannot, so the two families
+ * the reference actually instantiates are described by tables:
+ *
+ *   basis_fcn(state, input)  = Hilbert-space GP basis of src/BasisFunctions.py:8-80 evaluated at
+ *        v[sel[d]] with v = concat(state, input):   phi_m = nrm * prod_d sin(pi * idx[m][d] * r_d),
+ *        r_d = v[sel[d]] * alpha[d] + beta[d]
+ *        (alpha_d = 1/(div_d * 2 L_d), beta_d = (L_d - center_d)/(2 L_d), nrm = prod_d L_d^-1/2;
+ *         covers src/Toy_Example.py:146, src/EMPS.py:110-113, src/SingleMassOscillator.py:151).
+ *   likelihood_fcn(obs, state, input) = log N(obs; H state, R)
+ *        (src/Toy_Example.py:142-144, src/EMPS.py:250-252), given as H, LRinv = chol(R)^-1 and
+ *        cR = -ny/2 log(2 pi) - sum(log diag chol(R)).
+ */
+typedef struct pgas_model_desc {
+    int32_t N;            /* particles            (N_samples,   src/PGAS.py:26)  */
+    int32_t T;            /* time steps           (observations.shape[0], :159)  */
+    int32_t nx, ny, nu;   /* state / observation / input dimensions (nx<=2, ny<=2, nu<=4) */
+    int32_t M, D;         /* basis functions, basis input dimension (D<=3) */
+    const int32_t* idx;   /* host (M,D): frequency j of basis m in dimension d, reference order */
+    const int32_t* sel;   /* host (D)  */
+    const double* alpha;  /* host (D)  */
+    const double* beta;   /* host (D)  */
+    double nrm;
+    const double* H;      /* host (ny,nx) */
+    const double* LRinv;  /* host (ny,ny) lower triangular */
+    double cR;
+    const double* m0;     /* host (nx)      init_state_mean (src/PGAS.py:29) */
+    const double* L0;     /* host (nx,nx)   chol(init_state_cov) lower (src/PGAS.py:30) */
+    const double* y;      /* host (T,ny)    observations */
+    const double* u;      /* host (T,nu)    inputs; may be NULL when nu == 0 */
+    int32_t device;       /* HIP device ordinal */
+    int32_t keep_logw_trace; /* 1: keep the (T,N) log-weight trace like src/PGAS.py:163 (costs 8 B/particle-step) */
+} pgas_model_desc;
+
+/* Replaces condSequentialMonteCarlo.__init__ (src/PGAS.py:24-43) / PGAS.__init__ (:237-260):
+ * copies the model tables to the device.  Traces are allocated lazily by the first sweep. */
+int pgas_create(const pgas_model_desc* desc, pgas_ctx** out);
+void pgas_destroy(pgas_ctx* ctx);
+/* message of the last failing call on ctx (or of the last failing pgas_create when ctx == NULL) */
+const char* pgas_last_error(const pgas_ctx* ctx);
+
+/* Canonical-arithmetic constants the build was made with (segment length, fixed-point bits). */
+int32_t pgas_segment_size(void);
+
+/* Parameters of the transition x_t ~ N(A phi(x_{t-1},u_t), S) for the following step/sweep calls
+ * (coeff_mat, error_cov of src/PGAS.py:85-86,180-181).  A_dev: device (nx,M) row-major.
+ * LS_host = chol(S) lower (nx,nx), LSinv_host = LS^-1, cS = -nx/2 log(2 pi) - sum(log diag LS). */
+int pgas_set_params(pgas_ctx* ctx, const double* A_dev, const double* LS_host, const double* LSinv_host,
+                    double cS, void* stream);
+
+/* Test hook: phi (np,M) = basis_fcn(x[p], inputs[t]) in reference order
+ * (vmap(basis_fcn) of src/PGAS.py:52-54). x_dev (np,nx). */
+int pgas_basis_eval(pgas_ctx* ctx, const double* x_dev, int64_t np, int32_t t, double* phi_dev, void* stream);
+
+/* Test hook: aux (N,nx) = _generate_auxiliary_states (src/PGAS.py:45-57). */
+int pgas_aux_states(pgas_ctx* ctx, const double* x_dev, int32_t t, double* aux_dev, void* stream);
+
+/* condSequentialMonteCarlo._init_algorithm + the conditioning of :194: x0 (N,nx) ~ N(m0,P0),
+ * x0[N-1] = ref0 (host, nx). */
+int pgas_init_state(pgas_ctx* ctx, uint64_t seed, const double* ref0_host, double* x0_dev, void* stream);
+
+/* condSequentialMonteCarlo.step (src/PGAS.py:79-153): one conditional-SMC step at `time` = t.
+ * logw_dev (N) may be NULL (= zeros, the t = 1 case of :163); ref_t_host (nx).
+ * Outputs: logw_new_dev (N), x_new_dev (N,nx), anc_dev (N int32 = a_indices). */
+int pgas_step(pgas_ctx* ctx, int32_t t, uint64_t seed, const double* logw_dev, const double* x_dev,
+              const double* ref_t_host, double* logw_new_dev, double* x_new_dev, int32_t* anc_dev, void* stream);
+
+/* condSequentialMonteCarlo.__call__ (src/PGAS.py:176-228): the whole sweep incl. the final index
+ * draw (:224-225) and the back-trace (src/Filtering.py:40-55), all on the device.
+ * ref_dev (T,nx) in, traj_dev (T,nx) out. */
+int pgas_sweep(pgas_ctx* ctx, uint64_t seed, const double* ref_dev, double* traj_dev, void* stream);
+
+/* Device pointers of the traces of the last sweep: x_trace (T,N,nx), anc_trace (T-1,N) int32,
+ * logw_last (N) = log_weights_trace[T-1], logw_trace (T,N) or NULL.  Valid until the next sweep. */
+int pgas_get_traces(pgas_ctx* ctx, double** x_trace, int32_t** anc_trace, double** logw_last, double** logw_trace);
+
+/* Index drawn by the last sweep at src/PGAS.py:225 (synchronises the stream). */
+int pgas_last_final_index(pgas_ctx* ctx, int64_t* idx, void* stream);
+
+/* Sufficient statistics of PGAS.sample_params (src/PGAS.py:294-303, BI:53-61) without the prior:
+ * traj_dev (T,nx) -> T0 (M,nx), T1 (M,M) [fp64 MFMA SYRK], T2 (nx,nx); T3 = T-1.
+ * Pairs traj[:-1] with inputs[:-1] (quirk Q3). */
+int pgas_suffstats(pgas_ctx* ctx, const double* traj_dev, double* T0_dev, double* T1_dev, double* T2_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGAS_HIP_H */

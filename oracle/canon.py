@@ -140,9 +140,12 @@ class CanonModel:
             raise ValueError("oc_model_create rejected the model description")
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().oc_model_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().oc_model_destroy(self._h)
+                self._h = None
+        except Exception:  # interpreter shutdown
+            pass
 
     def grid(self):
         J, j0, js = (np.zeros(self.D, np.int32) for _ in range(3))
