@@ -35,7 +35,7 @@ class _ModelDesc(C.Structure):
 EXPORTS = [
     "pgas_create", "pgas_destroy", "pgas_last_error", "pgas_segment_size", "pgas_set_params", "pgas_basis_eval",
     "pgas_aux_states", "pgas_init_state", "pgas_step", "pgas_sweep", "pgas_get_traces", "pgas_last_final_index",
-    "pgas_suffstats",
+    "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile",
 ]
 
 _lib = None
@@ -75,6 +75,10 @@ def load():
     L.pgas_last_final_index.argtypes = [vp, C.POINTER(i64), vp]
     L.pgas_suffstats.restype = C.c_int
     L.pgas_suffstats.argtypes = [vp, vp, vp, vp, vp, vp]
+    L.pgas_set_profiling.restype = C.c_int
+    L.pgas_set_profiling.argtypes = [vp, i32]
+    L.pgas_get_profile.restype = C.c_int
+    L.pgas_get_profile.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), vp]
     _lib = L
     return L
 
@@ -225,6 +229,15 @@ class Engine:
         v = C.c_int64()
         self._chk(self.lib.pgas_last_final_index(self._h, C.byref(v), self._stream()), "pgas_last_final_index")
         return int(v.value)
+
+    def set_profiling(self, on):
+        self._chk(self.lib.pgas_set_profiling(self._h, 1 if on else 0), "pgas_set_profiling")
+
+    def profile(self):
+        """(launches, total_ms) of the dominant kernel in the last sweep (synchronises)."""
+        n, ms = C.c_int64(), C.c_double()
+        self._chk(self.lib.pgas_get_profile(self._h, C.byref(n), C.byref(ms), self._stream()), "pgas_get_profile")
+        return int(n.value), float(ms.value)
 
     def suffstats(self, traj):
         traj = self._dev(traj, shape=(self.T, self.nx))

@@ -84,6 +84,10 @@ struct pgas_ctx {
     double* logw_trace = nullptr;
     // suff-stat scratch
     double* d_phi = nullptr;
+    // optional per-launch timing of the dominant kernel (pgas_set_profiling)
+    int profiling = 0;
+    std::vector<hipEvent_t> ev;      // pairs (start, stop) around each k_fused launch of the last sweep
+    int ev_used = 0;
     std::string err;
 };
 
@@ -243,6 +247,7 @@ void pgas_destroy(pgas_ctx* c) {
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
     hipFree(c->d_phi);
+    for (hipEvent_t e : c->ev) hipEventDestroy(e);
     free_scanbufs(&c->sb[0]); free_scanbufs(&c->sb[1]);
     delete c;
 }
@@ -366,12 +371,20 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
         KCHK(c, "k_front");
         rc = launch_upper(c, c->sb[1], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, 1u), 0, st);
         if (rc) return rc;
+        c->ev_used = 0;
+        if (c->profiling && (int)c->ev.size() < 2 * T) {
+            const size_t old = c->ev.size();
+            c->ev.resize(2 * (size_t)T);
+            for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
+        }
         for (int t = 2; t < T; ++t) {
+            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], st));
             hipLaunchKernelGGL(c->var.fused, grid, blk, cm_bytes, st, md, c->tp, t, seed,
                                pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)), c->x_trace + (size_t)(t - 1) * row,
                                ref_dev + (size_t)t * nx, c->x_trace + (size_t)t * row, c->sb[(t - 1) & 1], c->sb[t & 1],
                                c->anc_trace + (size_t)(t - 2) * N, c->logw_trace ? c->logw_trace + (size_t)(t - 1) * N : (double*)nullptr);
             KCHK(c, "k_fused");
+            if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], st)); c->ev_used += 2; }
             rc = launch_upper(c, c->sb[t & 1], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
             if (rc) return rc;
         }
@@ -411,6 +424,28 @@ int pgas_last_final_index(pgas_ctx* c, int64_t* idx, void* stream) {
     UpperHdr h;
     HIPCHK(c, hipMemcpy(&h, c->sb[c->md.T & 1].hdr, sizeof h, hipMemcpyDeviceToHost));
     *idx = h.final_idx;
+    return PGAS_OK;
+}
+
+int pgas_set_profiling(pgas_ctx* c, int32_t on) {
+    if (!c) return PGAS_E_ARG;
+    c->profiling = on ? 1 : 0;
+    return PGAS_OK;
+}
+
+int pgas_get_profile(pgas_ctx* c, int64_t* launches, double* total_ms, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!launches || !total_ms) FAIL(c, PGAS_E_ARG, "pgas_get_profile: NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    double sum = 0.0;
+    for (int i = 0; i + 1 < c->ev_used; i += 2) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]));
+        sum += ms;
+    }
+    *launches = c->ev_used / 2;
+    *total_ms = sum;
     return PGAS_OK;
 }
 

@@ -119,15 +119,16 @@ def emps_pgas(T=2000, seed=12345678, M=729):
     return Problem("EMPS-PGAS", Y, tau, x0, P0, GaussianLikelihood.of_component(0, 2, R), bmap, prior, X)
 
 
-def initial_params(problem: Problem, seed=0):
-    """A reproducible (A, S) to run a sweep with: ridge fit of x_{t+1} on phi(x_t, u_t) along the true
-    trajectory (host NumPy, setup only) and S = residual covariance + small jitter."""
+def initial_params(problem: Problem):
+    """A reproducible, well-conditioned (A, S) to run a sweep with: the MNIW posterior given the true
+    trajectory (the deterministic part of PGAS.sample_params, src/PGAS.py:294-306): A = posterior mean,
+    S = row_scale / df.  Host NumPy, setup only."""
+    from .BayesianInferrence import prior_mniw_2naturalPara_inv
+
     T = problem.T
     u = problem.inputs
     Phi = np.stack([problem.basis_fcn(problem.X_true[t], u[t] if np.size(u) else None) for t in range(T - 1)])
     Xp = problem.X_true[1:]
-    lam = 1e-6 * np.trace(Phi.T @ Phi) / Phi.shape[1]
-    A = np.linalg.solve(Phi.T @ Phi + lam * np.eye(Phi.shape[1]), Phi.T @ Xp).T
-    res = Xp - Phi @ A.T
-    S = np.atleast_2d(np.cov(res.T)) + 1e-10 * np.eye(problem.nx)
-    return A, S
+    e0, e1, e2, e3 = problem.GP_prior
+    mean, _, row_scale, df = prior_mniw_2naturalPara_inv(e0 + Phi.T @ Xp, e1 + Phi.T @ Phi, e2 + Xp.T @ Xp, e3 + (T - 1))
+    return np.ascontiguousarray(mean), np.atleast_2d(row_scale) / df

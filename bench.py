@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""bench.py -- particle-steps/sec of the conditional-SMC sweep on the SingleMassOscillator-PGAS
+problem (BASELINE.json configs[1]: N = 2^20 particles, T = 2000, fp64, 1 x MI355X).
+
+A "step" of this bench is ONE conditional-SMC sweep (reference condSequentialMonteCarlo.__call__,
+src/PGAS.py:176-228): init, T-1 particle-filter steps with ancestor sampling, final index draw and
+back-trace, all on the device, including every trace write.  value = N (T-1) sweeps / wall.
+
+    python bench.py [--gpus G] [--steps K] [--warmup W] [--particles N] [--T T]
+
+With G > 1 (launched by torch.distributed.run, one rank per GPU) every rank runs the sweep on its
+own shard of work: see --mode.  Rank 0 prints one JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
+ALG_BYTES_PER_PARTICLE_STEP = 52  # 16 nx + 20, nx = 2
+
+
+def cpu_baseline(pb, A, S, N, seed, steps):
+    """Canonical C oracle (a port of the reference path, single thread) timed on this host for `steps` steps."""
+    from oracle import canon
+
+    bm, lik = pb.basis_fcn, pb.likelihood_fcn
+    y = np.asarray(pb.observations, dtype=np.float64).reshape(pb.T, -1)
+    u = np.asarray(pb.inputs, dtype=np.float64).reshape(pb.T, -1)
+    cm = canon.CanonModel(N, pb.T, pb.nx, y.shape[1], u.shape[1], bm.basis.indices, bm.sel, bm.alpha, bm.beta, bm.basis.norm,
+                          lik.H, lik.LRinv, lik.cR, y, u)
+    LS, LSinv, cS = cm.chol_parts(S)
+    L0 = np.linalg.cholesky(pb.init_state_cov)
+    t0 = time.perf_counter()
+    cm.sweep(seed, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, L0, traces=False, nsteps_limit=steps)
+    dt = time.perf_counter() - t0
+    return {
+        "value": N * steps / dt, "unit": "particle-steps/s", "cores": 1, "kind": "port",
+        "sample": f"canonical C oracle (oracle/pgas_canon.c, gcc -O2, 1 thread), N={N}, first {steps} of {pb.T - 1} steps, {dt:.1f} s; "
+                  f"host has {os.cpu_count()} logical CPUs",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--particles", type=int, default=1 << 20, help="particles per GPU")
+    ap.add_argument("--T", type=int, default=2000)
+    ap.add_argument("--cpu-steps", type=int, default=20, help="steps of the CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import pgas_amd
+    from pgas_amd import experiments
+
+    N, T = args.particles, args.T
+    seed = 12345678 + rank  # independent chains differ by seed (BASELINE config 5 convention: 12345678 + g)
+    pb = experiments.smo_pgas(T=T)
+    pg = pgas_amd.PGAS(N, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior,
+                       pb.basis_fcn, device=f"cuda:{local_rank}")
+    eng = pg.cSMC.engine
+    ref = torch.as_tensor(pb.X_true, device=eng.device)
+    # (A, S) from one sample_params on the initial reference trajectory
+    A, S = pg.sample_params(pgas_amd.random.key(seed), ref)
+    eng.set_profiling(not args.no_profile)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        pg.cSMC(seed + 1000 + w, ref, A, S)
+    barrier()
+    t0 = time.perf_counter()
+    prof_n, prof_ms = 0, 0.0
+    for k in range(args.steps):
+        pg.cSMC(seed + k, ref, A, S)
+        if not args.no_profile:
+            n, ms = eng.profile()   # synchronises this sweep; the events sit inside the timed region
+            prof_n += n
+            prof_ms += ms
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    units = N * (T - 1) * args.steps * world
+    out = {
+        "metric": "particle-steps/sec (N x (T-1) / wall), SingleMassOscillator PGAS conditional-SMC sweep",
+        "value": units / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"SingleMassOscillator PGAS sweep, N={N} particles/GPU, T={T}, nx=2, M=41 Hilbert basis, fp64 "
+                        f"(BASELINE.json configs[1])",
+            "particles_per_gpu": N, "T": T,
+            "parallelism": "1 GPU" if world == 1 else f"{world} independent chains, one per GPU, no data-path collective (replicas; "
+                                                       f"particle-sharded sweep is DESIGN.md section 7)",
+        },
+    }
+    if rank == 0:
+        if prof_n:
+            us = 1e3 * prof_ms / prof_n
+            achieved = ALG_BYTES_PER_PARTICLE_STEP * N / (us * 1e-6) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
+            if os.path.exists(tf):
+                traffic = json.load(open(tf)).get("k_fused_hbm_bytes_per_launch")
+            out["roofline"] = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "kernel": "k_fused<2,2,8,4>", "avg_launch_us": us, "launches": prof_n,
+                "alg_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * N,
+            }
+        if args.cpu_steps > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(pb, A.cpu().numpy(), S.cpu().numpy(), N, seed, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

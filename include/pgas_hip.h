@@ -117,6 +117,13 @@ int pgas_get_traces(pgas_ctx* ctx, double** x_trace, int32_t** anc_trace, double
 /* Index drawn by the last sweep at src/PGAS.py:225 (synchronises the stream). */
 int pgas_last_final_index(pgas_ctx* ctx, int64_t* idx, void* stream);
 
+/* Measurement aid (bench.py): when on, pgas_sweep brackets every launch of its dominant kernel
+ * (k_fused: resampling search of step t-1 + per-particle work of step t) with HIP events on the
+ * caller's stream; pgas_get_profile synchronises and returns their count and summed duration
+ * for the last sweep.  No reference counterpart (the reference has no timing code). */
+int pgas_set_profiling(pgas_ctx* ctx, int32_t on);
+int pgas_get_profile(pgas_ctx* ctx, int64_t* launches, double* total_ms, void* stream);
+
 /* Sufficient statistics of PGAS.sample_params (src/PGAS.py:294-303, BI:53-61) without the prior:
  * traj_dev (T,nx) -> T0 (M,nx), T1 (M,M) [fp64 MFMA SYRK], T2 (nx,nx); T3 = T-1.
  * Pairs traj[:-1] with inputs[:-1] (quirk Q3). */

@@ -1,0 +1,174 @@
+"""GPU parity tests: the HIP engine (through the C ABI, via pgas_amd) against the canonical C oracle.
+
+Bar: BIT-EXACT on every output (states, log-weights, ancestor indices, trajectory) -- the canonical
+arithmetic of DESIGN.md section 4 makes fp64 results reproducible across host and device.
+The oracle itself is pinned against the literal NumPy restatement of the reference in
+tests/test_oracle_canon.py (tolerance 1e-12, indices equal away from CDF ties).
+"""
+import numpy as np
+import pytest
+import torch
+
+from common import canon_model, experiments, pgas_amd
+
+pytestmark = pytest.mark.gpu
+
+SEED = 12345678
+
+
+def _problems():
+    return {
+        "smo": lambda: experiments.smo_pgas(T=40),
+        "toy": lambda: experiments.toy(T=40),
+        "emps": lambda: experiments.emps_pgas(T=10),
+        "emps27": lambda: experiments.emps_pgas(T=16, M=27),
+    }
+
+
+def _setup(name, N):
+    pb = _problems()[name]()
+    A, S = experiments.initial_params(pb)
+    cm = canon_model(pb, N)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn)
+    return pb, A, S, cm, csmc
+
+
+def _eq(gpu, ref, what):
+    g = gpu.cpu().numpy().reshape(np.shape(ref))
+    assert np.array_equal(g, ref), f"{what}: {int((g != ref).sum())} of {g.size} entries differ, max |d| = {np.abs(g - ref).max():.3e}"
+
+
+def test_library_loaded_is_in_tree():
+    from pgas_amd import _lib
+
+    _lib.load()
+    assert _lib.LIB_PATH.endswith("libpgas_hip.so")
+    maps = open("/proc/self/maps").read()
+    assert "libpgas_hip.so" in maps, "native library not mapped into the test process"
+
+
+@pytest.mark.parametrize("name,N", [("smo", 200), ("smo", 1024), ("smo", 1025), ("smo", 70000), ("toy", 777), ("emps", 1500), ("emps27", 3000)])
+def test_basis_init_step_bit_exact(name, N):
+    pb, A, S, cm, csmc = _setup(name, N)
+    eng = csmc.engine
+    LS, LSinv, cS = cm.chol_parts(S)
+    L0 = np.linalg.cholesky(pb.init_state_cov)
+    rng = np.random.default_rng(5)
+    xs = pb.X_true[rng.integers(0, pb.T, 257)] + 0.05 * rng.standard_normal((257, pb.nx))
+    _eq(eng.basis_eval(xs, 2), cm.basis_eval(xs, 2), "basis_eval")
+    x = cm.init_state(SEED, pb.init_state_mean, L0, pb.X_true[0])
+    _eq(eng.init_state(SEED, pb.X_true[0]), x, "init_state")
+    lw = None
+    for t in (1, 2, 3):
+        lwo, xo, ao, dbg = cm.step(t, SEED, x, lw, A, LS, LSinv, cS, pb.X_true[t], debug=True)
+        if t == 1:
+            eng.set_params(A, S)
+            _eq(eng.aux_states(x, t), dbg["aux"], "aux_states")
+        lwg, xg, ag = csmc.step(SEED, t, lw, x, A, S, pb.X_true[t])
+        _eq(xg, xo, f"step {t} new_state")
+        _eq(ag, ao, f"step {t} a_indices")
+        _eq(lwg, lwo, f"step {t} new_log_weights")
+        # conditional-SMC invariants
+        assert np.array_equal(xg[-1].cpu().numpy(), pb.X_true[t].reshape(-1))
+        assert np.all(np.diff(ag[:-1].cpu().numpy()) >= 0), "systematic resampling indices must be non-decreasing"
+        lw, x = lwo, xo
+
+
+@pytest.mark.parametrize("name,N", [("smo", 200), ("smo", 4096), ("smo", 5000), ("toy", 1500), ("emps", 2048), ("smo", 1 << 17)])
+def test_sweep_bit_exact(name, N):
+    pb, A, S, cm, csmc = _setup(name, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    traj = csmc(SEED, pb.X_true, A, S)
+    trajo, Xo, ANCo, lwo = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
+    X, ANC, LW, _ = csmc.engine.traces()
+    _eq(X, Xo, "state_trace")
+    _eq(ANC[: pb.T - 1], ANCo, "ancestor_trace")
+    _eq(LW, lwo, "log_weights_trace[-1]")
+    _eq(traj, trajo.reshape(traj.shape), "trajectory")
+    # the trajectory is a path through the trace (src/Filtering.py:40-55)
+    b = csmc.engine.last_final_index()
+    Xn, An = X.cpu().numpy(), ANC.cpu().numpy()
+    for t in range(pb.T - 1, -1, -1):
+        assert np.array_equal(Xn[t, b], trajo[t].reshape(-1))
+        if t:
+            b = An[t - 1, b]
+
+
+def test_sweep_degenerate_weights():
+    """One observation far from every particle: a handful of particles carry all the weight."""
+    pb = experiments.smo_pgas(T=12)
+    pb.observations = pb.observations.copy()
+    pb.observations[5] += 0.5  # ~16 sigma of R = 1e-3
+    N = 6000
+    A, S = experiments.initial_params(pb)
+    cm = canon_model(pb, N)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn)
+    LS, LSinv, cS = cm.chol_parts(S)
+    traj = csmc(SEED, pb.X_true, A, S)
+    trajo, Xo, ANCo, lwo = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
+    X, ANC, LW, _ = csmc.engine.traces()
+    _eq(ANC[: pb.T - 1], ANCo, "ancestor_trace")
+    _eq(traj, trajo, "trajectory")
+    assert len(np.unique(ANCo[4])) < N // 4  # the step really was degenerate
+
+
+def test_logw_trace_option():
+    pb = experiments.smo_pgas(T=8)
+    N = 3000
+    A, S = experiments.initial_params(pb)
+    cm = canon_model(pb, N)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn, keep_logw_trace=True)
+    LS, LSinv, cS = cm.chol_parts(S)
+    csmc(SEED, pb.X_true, A, S)
+    _, _, _, LT = csmc.engine.traces()
+    x = cm.init_state(SEED, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov), pb.X_true[0])
+    lw = None
+    assert float(LT[0].abs().max()) == 0.0
+    for t in range(1, pb.T):
+        lw, x, _ = cm.step(t, SEED, x, lw, A, LS, LSinv, cS, pb.X_true[t])
+        _eq(LT[t], lw, f"log_weights_trace[{t}]")
+
+
+def test_full_size_properties():
+    """BASELINE size N = 2^20 (T shortened): size-independent properties + oracle check of step 1."""
+    pb = experiments.smo_pgas(T=6)
+    N = 1 << 20
+    A, S = experiments.initial_params(pb)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn)
+    traj = csmc(SEED, pb.X_true, A, S)
+    X, ANC, LW, _ = csmc.engine.traces()
+    a = ANC[: pb.T - 1]
+    assert int(a.min()) >= 0 and int(a.max()) < N
+    assert bool((a[:, 1:-1] >= a[:, :-2]).all()), "resampled indices must be sorted"
+    assert torch.equal(X[:, -1, :], torch.as_tensor(pb.X_true, device=X.device)), "conditioned particle must follow the reference"
+    assert bool(torch.isfinite(LW).all())
+    # offspring counts of systematic resampling are within +-1 of N w, checked through the oracle on step 1
+    cm = canon_model(pb, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    x0 = cm.init_state(SEED, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov), pb.X_true[0])
+    lwo, xo, ao, dbg = cm.step(1, SEED, x0, None, A, LS, LSinv, cS, pb.X_true[1], debug=True)
+    _eq(X[1], xo, "x_trace[1] at N=2^20")
+    _eq(ANC[0], ao, "anc_trace[0] at N=2^20")
+    w = np.exp(dbg["lw1"] - dbg["lw1"].max())
+    w /= w.sum()
+    counts = np.bincount(ao[:-1], minlength=N)
+    counts[ao[-1]] += 0  # the conditioned slot is drawn separately (src/PGAS.py:127)
+    assert np.all(np.abs(counts - N * w) <= 2.0)
+    assert traj.shape == (pb.T, 2)
+
+
+def test_error_reporting():
+    pb = experiments.smo_pgas(T=5)
+    from pgas_amd._lib import PgasError
+
+    csmc = pgas_amd.condSequentialMonteCarlo(64, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn)
+    with pytest.raises(PgasError, match="set_params"):
+        csmc.engine.sweep(1, pb.X_true)
+    with pytest.raises(TypeError):
+        pgas_amd.condSequentialMonteCarlo(64, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                          lambda o, s, i: 0.0, pb.basis_fcn)

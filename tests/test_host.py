@@ -1,0 +1,76 @@
+"""Host logic of the package (no GPU): basis setup, descriptors, MNIW algebra, keys."""
+import numpy as np
+
+import pgas_amd
+from oracle import pgas_numpy as o
+from pgas_amd import experiments
+from pgas_amd import random as prng
+
+
+def test_generate_hilbert_basis_matches_restatement():
+    for args in ((41, np.array([[-7.5, 7.5], [-7.5, 7.5]]), 15 / 41, 100), (729, np.array([[-1, 1]] * 3), 0.5 / 729, 20),
+                 (40, np.array([-30, 30]), 3, 50), (20, np.array([-0.5, 0.5]), 0.1, 2.0, 2, 2)):
+        b, sd = pgas_amd.generate_Hilbert_BasisFunction(*args)
+        phi, sd2, S = o.generate_Hilbert_BasisFunction(*args)
+        assert np.array_equal(b.indices, S.astype(np.int32))
+        assert np.allclose(sd, sd2, rtol=1e-14)
+        x = np.full(b.D, 0.123)
+        assert np.allclose(b(x), phi(x if b.D > 1 else 0.123), rtol=1e-12, atol=1e-15)
+
+
+def test_basis_map_tables():
+    b, _ = pgas_amd.generate_Hilbert_BasisFunction(27, np.array([[-1, 1]] * 3), 0.1, 1.0)
+    bm = b.on([0, 1, 2], div=[0.4, 0.4, 160])
+    state, inp = np.array([0.1, -0.2]), np.array([35.0])
+    v = np.concatenate([state, inp])
+    r = v[bm.sel] * bm.alpha + bm.beta
+    direct = b.norm * np.prod(np.sin(np.pi * b.indices * r), axis=1)
+    assert np.allclose(bm(state, inp), direct, rtol=1e-12)
+
+
+def test_gaussian_likelihood_is_mvn_logpdf():
+    import scipy.stats as sst
+
+    lik = pgas_amd.GaussianLikelihood(np.array([[1.0, 0.5], [0.0, 2.0]]), np.array([[0.3, 0.1], [0.1, 0.2]]))
+    x, y = np.array([0.2, -0.4]), np.array([0.1, 0.3])
+    assert np.isclose(lik(y, x), sst.multivariate_normal.logpdf(y, lik.H @ x, lik.R))
+    l1 = pgas_amd.GaussianLikelihood.of_component(0, 2, np.array([[1e-3]]))
+    assert np.isclose(l1(0.05, x), sst.norm.logpdf(0.05, 0.2, np.sqrt(1e-3)))
+
+
+def test_mniw_host_functions_match_restatement():
+    rng = np.random.default_rng(1)
+    M, n = 6, 2
+    mean = rng.standard_normal((n, M))
+    V = np.diag(rng.random(M) + 0.5)
+    a = pgas_amd.prior_mniw_2naturalPara(mean, V, np.eye(n), 3)
+    b = o.prior_mniw_2naturalPara(mean, V, np.eye(n), 3)
+    for x, y in zip(a[:3], b[:3]):
+        assert np.allclose(x, y, rtol=1e-13)
+    ai = pgas_amd.prior_mniw_2naturalPara_inv(*a)
+    assert np.allclose(ai[0], mean) and np.allclose(ai[1], V) and np.allclose(ai[2], np.eye(n))
+    assert np.allclose(pgas_amd.prior_mniw_mean(a[0], a[1]), mean)
+    st = pgas_amd.prior_mniw_calcStatistics(np.array([1.0, 2.0]), np.arange(3.0))
+    assert st[0].shape == (3, 2) and st[1].shape == (3, 3) and st[2].shape == (2, 2) and st[3] == 1
+
+
+def test_keys_and_param_draws():
+    k = prng.key(12345678)
+    a, b = prng.split(k, 2)
+    assert a != b and prng.split(k, 2) == [a, b]
+    z = prng.normal(a, (200, 50))
+    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
+    c = prng.chisquare(b, np.array([2001.0, 2000.0, 0.7]))
+    assert 1800 < c[0] < 2200 and 1800 < c[1] < 2200 and c[2] > 0
+    draws = np.array([prng.chisquare(s, [5.0])[0] for s in prng.split(k, 400)])
+    assert abs(draws.mean() - 5.0) < 0.5
+
+
+def test_experiment_definitions():
+    pb = experiments.smo_pgas(T=60)
+    assert pb.basis_fcn.basis.M == 41 and pb.GP_prior[0].shape == (41, 2) and pb.GP_prior[1].shape == (41, 41)
+    assert pb.inputs[0] > 0 and pb.inputs[-1] < 0 and pb.inputs[30] == 0.0
+    e = experiments.emps_pgas(T=200)
+    assert e.basis_fcn.basis.M == 729 and np.abs(e.X_true[:, 0]).max() < 0.4 and np.abs(e.inputs).max() < 160
+    t = experiments.toy()
+    assert t.inputs.shape == (40, 0) and t.basis_fcn.basis.M == 40

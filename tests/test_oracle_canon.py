@@ -1,0 +1,121 @@
+"""Pins the canonical C oracle (oracle/pgas_canon.c) against the literal NumPy restatement of the
+reference (oracle/pgas_numpy.py) on identical random numbers, and against committed golden vectors.
+
+Tolerance: 1e-12 relative on continuous quantities (fp64 reordering only); ancestor indices must be
+equal except where U_i lies within 1e-9 of a CDF boundary ("index flips")."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from common import canon, canon_model, canon_rand, experiments, index_mismatch_is_tie, numpy_csmc, pgas_numpy
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+SEED = 12345678
+
+
+def _mk(name):
+    return {"smo": lambda: experiments.smo_pgas(T=30), "toy": lambda: experiments.toy(T=40),
+            "emps27": lambda: experiments.emps_pgas(T=10, M=27), "emps": lambda: experiments.emps_pgas(T=5)}[name]()
+
+
+@pytest.mark.parametrize("name,N", [("smo", 200), ("smo", 3000), ("toy", 500), ("emps27", 1500), ("emps", 200)])
+def test_teacher_forced_steps_match_numpy(name, N):
+    pb = _mk(name)
+    A, S = experiments.initial_params(pb)
+    cm, nm = canon_model(pb, N), numpy_csmc(pb, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    rand = canon_rand(SEED, N, pb.T, pb.nx)
+    x = cm.init_state(SEED, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov), pb.X_true[0])
+    assert np.allclose(x, nm.init_state(rand["z0"], pb.X_true[0]), rtol=1e-13, atol=1e-15)
+    lw = np.zeros(N)
+    for t in range(1, min(pb.T, 6)):
+        lwc, xc, ac, dbg = cm.step(t, SEED, x, lw, A, LS, LSinv, cS, pb.X_true[t], debug=True)
+        assert dbg["u"][0] == rand["u_resample"][t] and dbg["u"][1] == rand["u_ancestor"][t]
+        lwn, xn, an = nm.step(rand["u_resample"][t], rand["u_ancestor"][t], rand["z"][t], t, lw, x, A, S, pb.X_true[t])
+        scale = max(1.0, np.abs(xn).max())
+        assert np.abs(xc - xn).max() <= 1e-12 * scale
+        # weights: compare the resampling CDF inputs
+        Phi = nm.basis(x, nm.u[t])
+        ll_aux = nm.lik(nm.y[t], Phi @ A.T, nm.u[t])
+        assert np.abs(dbg["laux"] - ll_aux).max() <= 1e-9 * max(1.0, np.abs(ll_aux).max())
+        if not np.array_equal(ac[:-1], an[:-1]):
+            W = np.clip(np.cumsum(pgas_numpy.softmax(ll_aux + lw)), 0, 1)
+            U = (rand["u_resample"][t] + np.arange(N)) / N
+            assert index_mismatch_is_tie(ac[:-1], an[:-1], W, U[:-1])
+        same = ac == an
+        assert np.abs(lwc[same] - lwn[same]).max() <= 1e-8 * max(1.0, np.abs(lwn).max())
+        lw, x = lwc, xc  # teacher forcing: both sides continue from the canonical outputs
+
+
+# Toy: the learned map has slope |d aux/dx| ~ 40 (40 frequencies, |A| ~ 20), so rounding differences grow
+# geometrically along the sweep; its continuous tolerance is correspondingly looser.
+@pytest.mark.parametrize("name,N,tol", [("smo", 200, 1e-11), ("toy", 300, 1e-6)])
+def test_full_sweep_matches_numpy_small_N(name, N, tol):
+    pb = _mk(name)
+    A, S = experiments.initial_params(pb)
+    cm, nm = canon_model(pb, N), numpy_csmc(pb, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    traj, X, ANC, lw = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
+    trajn, Xn, LWn, ANCn, idx = nm(canon_rand(SEED, N, pb.T, pb.nx), pb.X_true, A, S, return_traces=True)
+    assert np.array_equal(ANC, ANCn[:-1].astype(np.int32))
+    assert idx == cm.final_index(SEED, lw)
+    assert np.abs(X[:4] - Xn[:4]).max() <= 1e-11 * max(1.0, np.abs(Xn).max())
+    assert np.abs(X - Xn).max() <= tol * max(1.0, np.abs(Xn).max())
+    assert np.abs(traj - trajn.reshape(traj.shape)).max() <= tol * max(1.0, np.abs(trajn).max())
+    assert np.abs(lw - LWn[-1]).max() <= 1e4 * tol
+
+
+def test_basis_eval_matches_reference_formula():
+    for name in ("smo", "toy", "emps27", "emps"):
+        pb = _mk(name)
+        cm, nm = canon_model(pb, 8), numpy_csmc(pb, 8)
+        rng = np.random.default_rng(3)
+        xs = pb.X_true[rng.integers(0, pb.T, 50)] + 0.1 * rng.standard_normal((50, pb.nx))
+        ref = nm.basis(xs, nm.u[2])
+        got = cm.basis_eval(xs, 2)
+        assert np.abs(got - ref).max() <= 2e-13 * np.abs(ref).max() * pb.basis_fcn.basis.indices.max()
+
+
+def test_pack_coeff_places_every_basis_function():
+    pb = _mk("emps")
+    cm = canon_model(pb, 8)
+    A = np.random.default_rng(0).standard_normal((2, cm.M))
+    G = cm.pack_coeff(A).reshape(2, -1)
+    assert np.count_nonzero(G) == 2 * cm.M
+    assert np.isclose(np.abs(G).sum(), np.abs(A * cm.nrm).sum())
+    J, j0, js = cm.grid()
+    assert J.tolist() == [11, 11, 11] and j0.tolist() == [1, 1, 1] and js.tolist() == [1, 1, 1]
+
+
+def test_resampling_edge_cases():
+    pb = experiments.smo_pgas(T=4)
+    N = 2500
+    cm = canon_model(pb, N)
+    # all weights equal -> identity map (u in (0,1)); one dominant weight -> everything maps to it
+    lw = np.zeros(N)
+    idx = cm.final_index(SEED, lw)
+    assert 0 <= idx < N
+    lw2 = np.full(N, -800.0)
+    lw2[1234] = 0.0
+    assert cm.final_index(SEED, lw2) == 1234
+    lw3 = np.full(N, -np.inf)
+    assert cm.final_index(SEED, lw3) == N - 1  # documented fallback when no weight is positive
+    lw4 = lw2.copy()
+    lw4[7] = np.nan  # NaN weights are ignored
+    assert cm.final_index(SEED, lw4) == 1234
+
+
+def test_golden_canonical_sweeps():
+    g = json.load(open(os.path.join(GOLD, "canon_sweeps.json")))
+    mk = {"smo": lambda: experiments.smo_pgas(T=10), "toy": lambda: experiments.toy(T=12), "emps27": lambda: experiments.emps_pgas(T=8, M=27)}
+    for name, spec in g.items():
+        pb = mk[name]()
+        A, S = experiments.initial_params(pb)
+        cm = canon_model(pb, spec["N"])
+        LS, LSinv, cS = cm.chol_parts(S)
+        traj, X, ANC, lw = cm.sweep(spec["seed"], pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
+        assert [float(v).hex() for v in traj.reshape(-1)] == spec["traj_hex"], name
+        assert ANC[-1].tolist() == spec["anc_last"] and [int(r.sum()) for r in ANC] == spec["anc_sum"], name
+        assert [float(v).hex() for v in lw[:8]] == spec["logw_last_hex"], name
