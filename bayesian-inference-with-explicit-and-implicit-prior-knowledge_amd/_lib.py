@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpgas_hip.so")
+LIB_PATH = os.environ.get("PGAS_HIP_LIB") or os.path.join(_HERE, "libpgas_hip.so")  # override: kernel experiments only
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
@@ -35,7 +35,7 @@ class _ModelDesc(C.Structure):
 EXPORTS = [
     "pgas_create", "pgas_destroy", "pgas_last_error", "pgas_segment_size", "pgas_set_params", "pgas_basis_eval",
     "pgas_aux_states", "pgas_init_state", "pgas_step", "pgas_sweep", "pgas_get_traces", "pgas_last_final_index",
-    "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile",
+    "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
 ]
 
 _lib = None
@@ -78,7 +78,9 @@ def load():
     L.pgas_set_profiling.restype = C.c_int
     L.pgas_set_profiling.argtypes = [vp, i32]
     L.pgas_get_profile.restype = C.c_int
-    L.pgas_get_profile.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), vp]
+    L.pgas_get_profile.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    L.pgas_set_option.restype = C.c_int
+    L.pgas_set_option.argtypes = [vp, i32, i64]
     _lib = L
     return L
 
@@ -234,10 +236,13 @@ class Engine:
         self._chk(self.lib.pgas_set_profiling(self._h, 1 if on else 0), "pgas_set_profiling")
 
     def profile(self):
-        """(launches, total_ms) of the dominant kernel in the last sweep (synchronises)."""
-        n, ms = C.c_int64(), C.c_double()
-        self._chk(self.lib.pgas_get_profile(self._h, C.byref(n), C.byref(ms), self._stream()), "pgas_get_profile")
-        return int(n.value), float(ms.value)
+        """(k_resample launches, their total ms, k_propagate total ms) of the last sweep (synchronises)."""
+        n, ms, pm = C.c_int64(), C.c_double(), C.c_double()
+        self._chk(self.lib.pgas_get_profile(self._h, C.byref(n), C.byref(ms), C.byref(pm), self._stream()), "pgas_get_profile")
+        return int(n.value), float(ms.value), float(pm.value)
+
+    def set_option(self, option, value):
+        self._chk(self.lib.pgas_set_option(self._h, int(option), int(value)), "pgas_set_option")
 
     def suffstats(self, traj):
         traj = self._dev(traj, shape=(self.T, self.nx))

@@ -17,8 +17,7 @@ namespace {
 thread_local std::string g_create_error;
 
 typedef void (*front_fn)(DevModel, TransParams, int, uint64_t, const double*, const double*, const double*, double*, ScanBufs);
-typedef void (*fused_fn)(DevModel, TransParams, int, uint64_t, double, const double*, const double*, double*, ScanBufs, ScanBufs,
-                         int32_t*, double*);
+typedef void (*prop_fn)(DevModel, TransParams, uint64_t, int, int, double*, const double*, double*, double*, double*);
 typedef void (*aux_fn)(DevModel, TransParams, int, const double*, double*);
 typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, int32_t*, double*);
 typedef void (*init_fn)(DevModel, uint64_t, const double*, const double*, double*);
@@ -26,31 +25,31 @@ typedef void (*basis_fn)(DevModel, const int32_t*, const double*, int64_t, int, 
 
 struct Variant {
     front_fn front;
-    fused_fn fused;
+    prop_fn prop;
     aux_fn aux;
 };
 
-template <int NX, int D, int JIN, int P>
+template <int NX, int D, int JIN, int P, int W>
 Variant make_variant() {
-    return Variant{k_front<NX, D, JIN, P>, k_fused<NX, D, JIN, P>, k_aux<NX, D, JIN, P>};
+    return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W>, k_aux<NX, D, JIN, P>};
 }
 
-// (nx, D, padded innermost extent) -> kernel instantiation
+// (nx, D, padded innermost extent) -> kernel instantiation <NX, D, JIN, P particles per basis pass, W waves/SIMD>
 bool pick_variant(int nx, int D, int jin_needed, Variant* v, int* JP) {
     if (D == 1) {
         *JP = 1;
-        *v = nx == 1 ? make_variant<1, 1, 1, 4>() : make_variant<2, 1, 1, 4>();
+        *v = nx == 1 ? make_variant<1, 1, 1, 4, 2>() : make_variant<2, 1, 1, 4, 2>();
         return true;
     }
     const int jp = jin_needed <= 8 ? 8 : jin_needed <= 12 ? 12 : jin_needed <= 16 ? 16 : 0;
     if (!jp) return false;
     *JP = jp;
     if (nx == 1) {
-        if (D == 2) *v = jp == 8 ? make_variant<1, 2, 8, 4>() : jp == 12 ? make_variant<1, 2, 12, 2>() : make_variant<1, 2, 16, 2>();
-        else *v = jp == 8 ? make_variant<1, 3, 8, 4>() : jp == 12 ? make_variant<1, 3, 12, 2>() : make_variant<1, 3, 16, 2>();
+        if (D == 2) *v = jp == 8 ? make_variant<1, 2, 8, 2, 2>() : jp == 12 ? make_variant<1, 2, 12, 2, 2>() : make_variant<1, 2, 16, 2, 2>();
+        else *v = jp == 8 ? make_variant<1, 3, 8, 2, 2>() : jp == 12 ? make_variant<1, 3, 12, 2, 2>() : make_variant<1, 3, 16, 2, 2>();
     } else {
-        if (D == 2) *v = jp == 8 ? make_variant<2, 2, 8, 4>() : jp == 12 ? make_variant<2, 2, 12, 2>() : make_variant<2, 2, 16, 2>();
-        else *v = jp == 8 ? make_variant<2, 3, 8, 4>() : jp == 12 ? make_variant<2, 3, 12, 2>() : make_variant<2, 3, 16, 2>();
+        if (D == 2) *v = jp == 8 ? make_variant<2, 2, 8, 2, 2>() : jp == 12 ? make_variant<2, 2, 12, 2, 2>() : make_variant<2, 2, 16, 2, 2>();
+        else *v = jp == 8 ? make_variant<2, 3, 8, 2, 2>() : jp == 12 ? make_variant<2, 3, 12, 2, 2>() : make_variant<2, 3, 16, 2, 2>();
     }
     return true;
 }
@@ -82,11 +81,24 @@ struct pgas_ctx {
     int32_t* anc_trace = nullptr;
     double* logw_last = nullptr;
     double* logw_trace = nullptr;
+    double* la_buf = nullptr;   // (T, nseg*SEG) log p(y_t | aux_t)      written by k_propagate
+    double* h_buf = nullptr;    // (T, nseg*SEG) log N(ref_t; aux_t, S)
+    double* ln_buf = nullptr;   // (T, nseg*SEG) log p(y_t | x_t)
+    double* laux_own[2] = {nullptr, nullptr};  // laux of the two step-API scan buffers
+    int prop_chunk = 0;         // time steps per k_propagate launch (0 = whole sweep)
+    unsigned launch_tag = 0;    // unique id per k_resample_fast launch (hand-off word tag)
+    int force_slow = 0;         // 1: never use k_resample_fast (test hook for the k_resample + k_upper path)
+    int overlap = 1;            // 1: run the weight recursion on an internal stream concurrently with k_propagate
+    hipStream_t sB = nullptr;   // internal high-priority stream of the weight recursion
+    std::vector<hipEvent_t> ev_chunk;  // "k_propagate chunk c done" events
+    hipEvent_t ev_start = nullptr, ev_done = nullptr;
     // suff-stat scratch
     double* d_phi = nullptr;
     // optional per-launch timing of the dominant kernel (pgas_set_profiling)
     int profiling = 0;
-    std::vector<hipEvent_t> ev;      // pairs (start, stop) around each k_fused launch of the last sweep
+    std::vector<hipEvent_t> ev;      // pairs (start, stop) around each k_resample launch of the last sweep
+    hipEvent_t ev_prop[2] = {nullptr, nullptr};  // around the k_propagate launches
+    int prop_steps = 0;
     int ev_used = 0;
     std::string err;
 };
@@ -174,7 +186,7 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
         for (int m = 0; m < d->M; ++m)
             if ((d->idx[m * d->D + k] - lo) % md.jstep[k]) FAIL(c, PGAS_E_ARG, "pgas_create: idx column %d is not an arithmetic progression", k);
         md.J[k] = (hi - lo) / md.jstep[k] + 1;
-        if (md.J[k] > PGAS_MAX_J && !(d->D == 1)) FAIL(c, PGAS_E_ARG, "pgas_create: %d frequencies in dimension %d (max %d)", md.J[k], k, PGAS_MAX_J);
+        if (md.J[k] > PGAS_MAX_J) FAIL(c, PGAS_E_ARG, "pgas_create: %d frequencies in dimension %d (max %d)", md.J[k], k, PGAS_MAX_J);
     }
     for (int j = 0; j < d->ny; ++j)
         for (int k = 0; k < d->nx; ++k) md.H[j * d->nx + k] = d->H[j * d->nx + k];
@@ -221,9 +233,6 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
         int rc = alloc_scanbufs(c, &c->sb[i]);
         if (rc) return rc;
     }
-    const size_t ub = upper_smem_bytes(md.nseg);
-    if (ub > 48 * 1024)
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void*>(k_upper), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ub));
     return PGAS_OK;
 }
 
@@ -246,8 +255,13 @@ void pgas_destroy(pgas_ctx* c) {
     hipSetDevice(c->device);
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
-    hipFree(c->d_phi);
+    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_prop) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
+    if (c->ev_start) hipEventDestroy(c->ev_start);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->sB) hipStreamDestroy(c->sB);
     free_scanbufs(&c->sb[0]); free_scanbufs(&c->sb[1]);
     delete c;
 }
@@ -306,8 +320,9 @@ int pgas_init_state(pgas_ctx* c, uint64_t seed, const double* ref0_host, double*
 }
 
 static int launch_upper(pgas_ctx* c, const ScanBufs& sb, int nblocks, int search_block, double u, int final_mode, hipStream_t st) {
-    hipLaunchKernelGGL(k_upper, dim3(nblocks), dim3(PG_UPPER_THREADS), upper_smem_bytes(c->md.nseg), st, c->md.N, c->md.nseg, sb,
-                       search_block, u, final_mode);
+    const int groups = (c->md.nseg + 63) / 64;
+    auto kern = groups <= 4 * PG_UPPER_WAVES ? k_upper<4> : groups <= 8 * PG_UPPER_WAVES ? k_upper<8> : k_upper<PG_MAX_GROUPS / PG_UPPER_WAVES>;
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(PG_UPPER_THREADS), 0, st, c->md.N, c->md.nseg, sb, search_block, u, final_mode);
     KCHK(c, "k_upper");
     return PGAS_OK;
 }
@@ -326,7 +341,7 @@ int pgas_step(pgas_ctx* c, int32_t t, uint64_t seed, const double* logw_dev, con
     KCHK(c, "k_front");
     int rc = launch_upper(c, c->sb[0], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(c->back, dim3(md.nseg), dim3(PG_BLK), md.nseg * sizeof(double), st, md, t,
+    hipLaunchKernelGGL(c->back, dim3(md.nseg), dim3(PG_BLK), 0, st, md, t,
                        pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), x_new_dev, c->sb[0], anc_dev, logw_new_dev);
     KCHK(c, "k_back");
     return PGAS_OK;
@@ -339,6 +354,10 @@ static int ensure_traces(pgas_ctx* c) {
     HIPCHK(c, hipMalloc(&c->x_trace, (size_t)md.T * row * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->anc_trace, (size_t)(md.T > 1 ? md.T - 1 : 1) * md.N * sizeof(int32_t)));
     HIPCHK(c, hipMalloc(&c->logw_last, (size_t)md.N * sizeof(double)));
+    const size_t np = (size_t)md.nseg * PGAS_SEG;
+    HIPCHK(c, hipMalloc(&c->la_buf, (size_t)md.T * np * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->h_buf, (size_t)md.T * np * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->ln_buf, (size_t)md.T * np * sizeof(double)));
     if (c->keep_logw) {
         HIPCHK(c, hipMalloc(&c->logw_trace, (size_t)md.T * md.N * sizeof(double)));
         HIPCHK(c, hipMemset(c->logw_trace, 0, (size_t)md.T * md.N * sizeof(double)));
@@ -358,39 +377,92 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     const int N = md.N, T = md.T, nx = md.nx;
     const size_t row = (size_t)N * nx;
     const dim3 grid(md.nseg), blk(PG_BLK);
-    const size_t cm_bytes = md.nseg * sizeof(double);
 
     hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, c->x_trace);
     KCHK(c, "k_init");
+    c->ev_used = 0;
+    c->prop_steps = 0;
     if (T == 1) {
         HIPCHK(c, hipMemsetAsync(c->logw_last, 0, N * sizeof(double), st));
     } else {
-        // t = 1: log-weights are zero (src/PGAS.py:163), nothing to resample yet
-        hipLaunchKernelGGL(c->var.front, grid, blk, 0, st, md, c->tp, 1, seed, c->x_trace, (const double*)nullptr, ref_dev + nx,
-                           c->x_trace + row, c->sb[1]);
-        KCHK(c, "k_front");
-        rc = launch_upper(c, c->sb[1], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, 1u), 0, st);
-        if (rc) return rc;
-        c->ev_used = 0;
-        if (c->profiling && (int)c->ev.size() < 2 * T) {
-            const size_t old = c->ev.size();
-            c->ev.resize(2 * (size_t)T);
-            for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
+        const size_t np = (size_t)md.nseg * PGAS_SEG;
+        if (c->profiling) {
+            if ((int)c->ev.size() < 2 * T) {
+                const size_t old = c->ev.size();
+                c->ev.resize(2 * (size_t)T);
+                for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
+            }
+            for (hipEvent_t& e : c->ev_prop) if (!e) HIPCHK(c, hipEventCreate(&e));
+            HIPCHK(c, hipEventRecord(c->ev_prop[0], st));
         }
-        for (int t = 2; t < T; ++t) {
-            if (c->profiling) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], st));
-            hipLaunchKernelGGL(c->var.fused, grid, blk, cm_bytes, st, md, c->tp, t, seed,
-                               pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)), c->x_trace + (size_t)(t - 1) * row,
-                               ref_dev + (size_t)t * nx, c->x_trace + (size_t)t * row, c->sb[(t - 1) & 1], c->sb[t & 1],
-                               c->anc_trace + (size_t)(t - 2) * N, c->logw_trace ? c->logw_trace + (size_t)(t - 1) * N : (double*)nullptr);
-            KCHK(c, "k_fused");
-            if (c->profiling) { HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], st)); c->ev_used += 2; }
-            rc = launch_upper(c, c->sb[t & 1], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
-            if (rc) return rc;
+        // pipeline A (caller's stream): every particle through all time steps; independent of the weights (quirk Q1).
+        // pipeline B (internal high-priority stream when overlap is on): the weight recursion, gated chunk by chunk on
+        // pipeline A by events, so that its latency-bound launches run underneath k_propagate's arithmetic.
+        const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 2 : T);
+        const int nchunk = (T - 1 + chunk - 1) / chunk;
+        hipStream_t sb_stream = st;
+        if (c->overlap) {
+            if (!c->sB) {
+                int lo = 0, hi = 0;
+                HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+                HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, hi));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+            }
+            while ((int)c->ev_chunk.size() < nchunk) {
+                hipEvent_t e;
+                HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                c->ev_chunk.push_back(e);
+            }
+            sb_stream = c->sB;
+            HIPCHK(c, hipEventRecord(c->ev_start, st));
+            HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_start, 0));
         }
-        hipLaunchKernelGGL(c->back, grid, blk, cm_bytes, st, md, T - 1, pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(T - 1)),
-                           c->x_trace + (size_t)(T - 1) * row, c->sb[(T - 1) & 1], c->anc_trace + (size_t)(T - 2) * N, c->logw_last);
-        KCHK(c, "k_back");
+        const bool fast = md.nseg <= PG_FAST_NSEG && !c->force_slow;
+        // launches are issued chunk by chunk, pipeline A first, so both device queues stay fed
+        for (int ci = 0; ci < nchunk; ++ci) {
+            const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+            hipLaunchKernelGGL(c->var.prop, grid, blk, 0, st, md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
+            KCHK(c, "k_propagate");
+            if (c->overlap) {
+                HIPCHK(c, hipEventRecord(c->ev_chunk[ci], st));
+                HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_chunk[ci], 0));
+            }
+            if (ci == nchunk - 1 && c->profiling) HIPCHK(c, hipEventRecord(c->ev_prop[1], st));
+            // launch t resamples step t-1 (t > 1) and scans step t (t < T); the last chunk also runs launch T
+            const int tend = ci == nchunk - 1 ? T + 1 : t1;
+            for (int t = t0; t < tend; ++t) {
+                ScanBufs sp = c->sb[(t - 1) & 1], sn = c->sb[t & 1];
+                sp.laux = c->la_buf + (size_t)(t - 1) * np;
+                sn.laux = c->la_buf + (size_t)(t < T ? t : T - 1) * np;
+                const int mode = (t < T ? PG_RS_SCAN : 0) | (t > 1 ? PG_RS_SEARCH : 0);
+                const double u1p = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)) : 0.0;
+                const double u2p = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)(t - 1)) : 0.0;
+                const double* la_t = t < T ? c->la_buf + (size_t)t * np : (const double*)nullptr;
+                const double* h_t = t < T ? c->h_buf + (size_t)t * np : (const double*)nullptr;
+                int32_t* anc = t > 1 ? c->anc_trace + (size_t)(t - 2) * N : (int32_t*)nullptr;
+                double* lwo = t == T ? c->logw_last : ((c->logw_trace && t > 1) ? c->logw_trace + (size_t)(t - 1) * N : (double*)nullptr);
+                const bool timed = c->profiling && t < T;
+                if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], sb_stream));
+                if (fast) {
+                    hipLaunchKernelGGL(k_resample_fast, dim3(md.nseg + 1), blk, 0, sb_stream, md, t, mode, ++c->launch_tag, u1p, u2p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
+                    KCHK(c, "k_resample_fast");
+                } else {
+                    hipLaunchKernelGGL(k_resample, grid, blk, 0, sb_stream, md, t, mode, u1p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
+                    KCHK(c, "k_resample");
+                }
+                if (timed) { HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], sb_stream)); c->ev_used += 2; }
+                if (!fast && t < T) {
+                    rc = launch_upper(c, sn, 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, sb_stream);
+                    if (rc) return rc;
+                }
+            }
+        }
+        c->prop_steps = T - 1;
+        if (c->overlap) {
+            HIPCHK(c, hipEventRecord(c->ev_done, c->sB));
+            HIPCHK(c, hipStreamWaitEvent(st, c->ev_done, 0));
+        }
         if (c->logw_trace)
             HIPCHK(c, hipMemcpyAsync(c->logw_trace + (size_t)(T - 1) * N, c->logw_last, N * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
@@ -433,9 +505,27 @@ int pgas_set_profiling(pgas_ctx* c, int32_t on) {
     return PGAS_OK;
 }
 
-int pgas_get_profile(pgas_ctx* c, int64_t* launches, double* total_ms, void* stream) {
+int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
     if (!c) return PGAS_E_ARG;
-    if (!launches || !total_ms) FAIL(c, PGAS_E_ARG, "pgas_get_profile: NULL argument");
+    if (option == PGAS_OPT_PROPAGATE_CHUNK) {
+        if (value < 0) FAIL(c, PGAS_E_ARG, "pgas_set_option: chunk must be >= 0");
+        c->prop_chunk = (int)value;
+        return PGAS_OK;
+    }
+    if (option == PGAS_OPT_FORCE_SLOW_RESAMPLE) {
+        c->force_slow = value ? 1 : 0;
+        return PGAS_OK;
+    }
+    if (option == PGAS_OPT_OVERLAP) {
+        c->overlap = value ? 1 : 0;
+        return PGAS_OK;
+    }
+    FAIL(c, PGAS_E_ARG, "pgas_set_option: unknown option %d", option);
+}
+
+int pgas_get_profile(pgas_ctx* c, int64_t* launches, double* total_ms, double* propagate_ms, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!launches || !total_ms || !propagate_ms) FAIL(c, PGAS_E_ARG, "pgas_get_profile: NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
     double sum = 0.0;
@@ -446,8 +536,20 @@ int pgas_get_profile(pgas_ctx* c, int64_t* launches, double* total_ms, void* str
     }
     *launches = c->ev_used / 2;
     *total_ms = sum;
+    *propagate_ms = 0.0;
+    if (c->prop_steps > 0 && c->ev_prop[0]) {
+        float ms = 0.f;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_prop[0], c->ev_prop[1]));
+        *propagate_ms = ms;
+    }
     return PGAS_OK;
 }
+
+#ifdef PG_STAMPS
+int pgas_debug_stamps(unsigned long long* out /* 2048*16 */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 2048 * 16) == hipSuccess ? 0 : -2;
+}
+#endif
 
 int pgas_suffstats(pgas_ctx* c, const double* traj_dev, double* T0_dev, double* T1_dev, double* T2_dev, void* stream) {
     if (!c) return PGAS_E_ARG;

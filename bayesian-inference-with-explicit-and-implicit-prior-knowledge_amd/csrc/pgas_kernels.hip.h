@@ -8,7 +8,8 @@
 //   k_upper       cross-segment CDF (2 blocks: resampling CDF, ancestor CDF + ancestor search)
 //                                                                   src/PGAS.py:102,118,121-127
 //   k_back        systematic resampling search + weight update      src/Filtering.py:28-35, src/PGAS.py:137-147
-//   k_fused       k_back(t-1) + k_front(t) in one launch (the sweep's steady state)
+//   k_propagate   every particle through a range of time steps, state in registers (no synchronisation)
+//   k_resample    per step: resampling search of step t-1, weight update, softmax scans of step t
 //   k_segscan     softmax scan of a weight vector (final index)     src/PGAS.py:224
 //   k_backtrace   ancestor chase                                    src/Filtering.py:40-55
 //   k_basis_eval  phi(x) in reference order (test hook)             src/BasisFunctions.py:77-80
@@ -25,9 +26,23 @@
 
 #define PG_BLK 256
 #define PG_PPT 4
-static_assert(PG_BLK * PG_PPT == PGAS_SEG, "one workgroup owns one canonical segment");
-#define PG_UPPER_THREADS 1024
+static_assert(PG_BLK * PG_PPT == PGAS_SEG && PGAS_SEG == 1024, "one workgroup owns one canonical segment of 1024 particles");
+#define PG_UPPER_THREADS 256
+// W (template parameter of k_propagate) = workgroups resident per CU (= waves per SIMD it is compiled for):
+// N = 2^20 is exactly 4 segments per CU, so the 1- and 2-dimensional bases are built for W = 4.
 #define PG_MAX_NSEG 8192
+
+// Diagnostic build only (-DPG_STAMPS): per-workgroup wall-clock stamps (100 MHz s_memrealtime) at phase boundaries of
+// k_resample_fast, read back with pgas_debug_stamps.  No stamp executes in the product build.
+#ifdef PG_STAMPS
+__device__ unsigned long long g_stamps[2048 * 16];
+#define PG_STAMP(id)                                                                                \
+    do {                                                                                            \
+        if (threadIdx.x == 0) g_stamps[blockIdx.x * 16 + (id)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define PG_STAMP(id) do { } while (0)
+#endif
 
 struct DevModel {
     int32_t N, T, nx, ny, nu, D, M;
@@ -53,6 +68,7 @@ struct UpperHdr {      // written by k_upper
     int32_t valid[2];
     int32_t ref_idx;
     int32_t final_idx;
+    unsigned long long ref_granule;  // k_resample_fast: {launch tag : 32, ancestor of the conditioned particle : 32}, one 8-byte store
 };
 
 struct ScanBufs {      // per-step scan scratch (device)
@@ -71,43 +87,75 @@ struct ScanBufs {      // per-step scan scratch (device)
 // ------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------
+// ---- wave-level primitives on DPP (data-parallel primitives: VALU-latency lane exchange, no LDS round trip) ----------
+// row_shr:n shifts inside each row of 16 lanes, row_bcast:15 / row_bcast:31 feed a row's / half-wave's last lane to the
+// following row(s).  Lanes without a source read 0 (`old` = 0 with bound_ctrl / row masks), and adding 0.0 is exact.
+#define PG_DPP_ROW_SHR(n) (0x110 + (n))
+#define PG_DPP_ROW_BCAST15 0x142
+#define PG_DPP_ROW_BCAST31 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_u64(uint64_t v) {
+    int lo = (int)(uint32_t)v, hi = (int)(uint32_t)(v >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, true);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane_uniform) {
+    const int l = __builtin_amdgcn_readfirstlane(lane_uniform);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+// Canonical inclusive scan of one group of 64 doubles ("R16 tree"): Kogge-Stone inside each row of
+// 16 lanes (offsets 1,2,4,8), then rows 1,3 add the total of the row before, then rows 2,3 add lane 31's value.
+__device__ __forceinline__ double wave_scan_add(double v) {
+    v = v + dpp_f64<PG_DPP_ROW_SHR(1), 0xf>(v);
+    v = v + dpp_f64<PG_DPP_ROW_SHR(2), 0xf>(v);
+    v = v + dpp_f64<PG_DPP_ROW_SHR(4), 0xf>(v);
+    v = v + dpp_f64<PG_DPP_ROW_SHR(8), 0xf>(v);
+    v = v + dpp_f64<PG_DPP_ROW_BCAST15, 0xa>(v);
+    v = v + dpp_f64<PG_DPP_ROW_BCAST31, 0xc>(v);
+    return v;
+}
+// inclusive running maximum of non-negative values (exact in any order; same exchange pattern)
+__device__ __forceinline__ double wave_scan_max(double v) {
+    v = __builtin_fmax(v, dpp_f64<PG_DPP_ROW_SHR(1), 0xf>(v));
+    v = __builtin_fmax(v, dpp_f64<PG_DPP_ROW_SHR(2), 0xf>(v));
+    v = __builtin_fmax(v, dpp_f64<PG_DPP_ROW_SHR(4), 0xf>(v));
+    v = __builtin_fmax(v, dpp_f64<PG_DPP_ROW_SHR(8), 0xf>(v));
+    v = __builtin_fmax(v, dpp_f64<PG_DPP_ROW_BCAST15, 0xa>(v));
+    v = __builtin_fmax(v, dpp_f64<PG_DPP_ROW_BCAST31, 0xc>(v));
+    return v;
+}
+// inclusive integer scan (exact in any order)
+__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
+    v += dpp_u64<PG_DPP_ROW_SHR(1), 0xf>(v);
+    v += dpp_u64<PG_DPP_ROW_SHR(2), 0xf>(v);
+    v += dpp_u64<PG_DPP_ROW_SHR(4), 0xf>(v);
+    v += dpp_u64<PG_DPP_ROW_SHR(8), 0xf>(v);
+    v += dpp_u64<PG_DPP_ROW_BCAST15, 0xa>(v);
+    v += dpp_u64<PG_DPP_ROW_BCAST31, 0xc>(v);
+    return v;
+}
+// maximum over the wave (NaN ignored, any sign): butterfly in the row, then across rows through lane reads
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = __builtin_fmax(v, __shfl_xor(v, off));
     return v;
 }
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        int o = __shfl_xor(v, off);
-        v = o < v ? o : v;
-    }
-    return v;
-}
-__device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint64_t o = __shfl_up((unsigned long long)v, off);
-        if (lane >= off) v += o;
-    }
-    return v;
-}
-// canonical Kogge-Stone inclusive scan of one group of 64
-__device__ __forceinline__ double wave_ks_add(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        double o = __shfl_up(v, off);
-        if (lane >= off) v = v + o;
-    }
-    return v;
-}
-__device__ __forceinline__ double wave_ks_max(double v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        double o = __shfl_up(v, off);
-        if (lane >= off) v = __builtin_fmax(v, o);
-    }
-    return v;
+__device__ __forceinline__ int wave_sum_i(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, PG_DPP_ROW_SHR(1), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, PG_DPP_ROW_SHR(2), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, PG_DPP_ROW_SHR(4), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, PG_DPP_ROW_SHR(8), 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, PG_DPP_ROW_BCAST15, 0xa, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, PG_DPP_ROW_BCAST31, 0xc, 0xf, true);
+    return __builtin_amdgcn_readlane(v, 63);
 }
 
 template <int NX>
@@ -144,10 +192,38 @@ __device__ __forceinline__ double loglik(const DevModel& md, const double* __res
     return PGAS_FMA(-0.5, quad, md.cR);
 }
 
-// sin/cos of the first frequency and of the frequency step of basis dimension d
-__device__ __forceinline__ void dim_start(const DevModel& md, int d, double r, double& sc, double& cc, double& sd, double& cd) {
-    pgas_sincospi((double)md.j0[d] * r, &sc, &cc);
-    pgas_sincospi((double)md.jstep[d] * r, &sd, &cd);
+// ---- per-dimension sines sin(pi (j0 + q step) r), q = 0.. (src/BasisFunctions.py:77-80) ------------------
+// canonical recurrences:
+//   D == 1 : rotation   (s,c) <- (s cd + c sd, c cd - s sd)          (stable for the 40-frequency Toy basis)
+//   D >= 2 : Chebyshev  s_{q+1} = 2 cd s_q - s_{q-1},  s_{-1} = sin(pi (j0 - step) r)  (= 0 when j0 == step)
+struct DimStart {
+    double s0, c0, sd, cd;
+};
+
+// start / step sines of dimension d for P particles at once (batch form keeps polynomial coefficients in registers)
+template <int P>
+__device__ __forceinline__ void dim_start_n(const DevModel& md, int d, const double (&r)[P], DimStart (&ds)[P]) {
+    double a[P], sv[P], cv[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) a[p] = (double)md.j0[d] * r[p];
+    pgas_sincospi_n(a, sv, cv, P);
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        ds[p].s0 = sv[p];
+        ds[p].c0 = cv[p];
+        ds[p].sd = sv[p];
+        ds[p].cd = cv[p];
+    }
+    if (md.jstep[d] != md.j0[d]) {  // uniform
+#pragma unroll
+        for (int p = 0; p < P; ++p) a[p] = (double)md.jstep[d] * r[p];
+        pgas_sincospi_n(a, sv, cv, P);
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            ds[p].sd = sv[p];
+            ds[p].cd = cv[p];
+        }
+    }
 }
 __device__ __forceinline__ void rotate(double& sc, double& cc, double sd, double cd) {
     double sn = PGAS_FMA(sc, cd, cc * sd);
@@ -155,25 +231,42 @@ __device__ __forceinline__ void rotate(double& sc, double& cc, double sd, double
     sc = sn;
     cc = cn;
 }
+// Chebyshev state of one dimension: cur = s_q, prev = s_{q-1}, tw = 2 cd
+struct Cheb {
+    double cur, prev, tw;
+};
+__device__ __forceinline__ Cheb cheb_init(const DevModel& md, int d, const DimStart& ds) {
+    Cheb c;
+    c.cur = ds.s0;
+    c.prev = (md.jstep[d] == md.j0[d]) ? 0.0 : PGAS_FMA(ds.s0, ds.cd, -(ds.c0 * ds.sd));
+    c.tw = ds.cd + ds.cd;
+    return c;
+}
+__device__ __forceinline__ void cheb_next(Cheb& c) {
+    const double nx = PGAS_FMA(c.tw, c.cur, -c.prev);
+    c.prev = c.cur;
+    c.cur = nx;
+}
 
 // ------------------------------------------------------------------------------------------
 // aux = A phi(x, u_t) for P particles at once (src/PGAS.py:52-55).  The basis is separable
 // (src/BasisFunctions.py:77-80), so the M products collapse into a nested contraction over the
 // dense frequency grid; the coefficients are wave-uniform (scalar loads), the outer dimensions'
-// sines come from a rotation recurrence, only the innermost dimension's table lives in registers.
+// sines come from a recurrence, only the innermost dimension's table lives in registers.
 // ------------------------------------------------------------------------------------------
 template <int NX, int D, int JIN, int P>
 __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __restrict__ G, const double* __restrict__ ut,
                                           const double (&x)[P][NX], double (&aux)[P][NX]) {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+        for (int k = 0; k < NX; ++k) aux[p][k] = 0.0;
     if constexpr (D == 1) {
-        double sc[P], cc[P], sd[P], cd[P];
+        double r[P];
+        DimStart ds[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            double r = PGAS_FMA(pick_input<NX>(md, 0, x[p], ut), md.alpha[0], md.beta[0]);
-            dim_start(md, 0, r, sc[p], cc[p], sd[p], cd[p]);
-#pragma unroll
-            for (int k = 0; k < NX; ++k) aux[p][k] = 0.0;
-        }
+        for (int p = 0; p < P; ++p) r[p] = PGAS_FMA(pick_input<NX>(md, 0, x[p], ut), md.alpha[0], md.beta[0]);
+        dim_start_n<P>(md, 0, r, ds);
         const int J0 = md.J[0];
         for (int a = 0; a < J0; ++a) {
             double g[NX];
@@ -182,32 +275,35 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
 #pragma unroll
             for (int p = 0; p < P; ++p) {
 #pragma unroll
-                for (int k = 0; k < NX; ++k) aux[p][k] = PGAS_FMA(g[k], sc[p], aux[p][k]);
-                rotate(sc[p], cc[p], sd[p], cd[p]);
+                for (int k = 0; k < NX; ++k) aux[p][k] = PGAS_FMA(g[k], ds[p].s0, aux[p][k]);
+                rotate(ds[p].s0, ds[p].c0, ds[p].sd, ds[p].cd);
             }
         }
     } else {
         // innermost dimension table
         constexpr int DI = D - 1;
         double tab[P][JIN];
+        Cheb c0[P];
+        {
+            double rin[P], rout[P];
+            DimStart din[P], dout[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            double r = PGAS_FMA(pick_input<NX>(md, DI, x[p], ut), md.alpha[DI], md.beta[DI]);
-            double sc, cc, sd, cd;
-            dim_start(md, DI, r, sc, cc, sd, cd);
-#pragma unroll
-            for (int q = 0; q < JIN; ++q) {
-                tab[p][q] = sc;
-                rotate(sc, cc, sd, cd);
+            for (int p = 0; p < P; ++p) {
+                rin[p] = PGAS_FMA(pick_input<NX>(md, DI, x[p], ut), md.alpha[DI], md.beta[DI]);
+                rout[p] = PGAS_FMA(pick_input<NX>(md, 0, x[p], ut), md.alpha[0], md.beta[0]);
             }
-        }
-        double s0[P], c0[P], sd0[P], cd0[P];
+            dim_start_n<P>(md, DI, rin, din);
+            dim_start_n<P>(md, 0, rout, dout);
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            double r = PGAS_FMA(pick_input<NX>(md, 0, x[p], ut), md.alpha[0], md.beta[0]);
-            dim_start(md, 0, r, s0[p], c0[p], sd0[p], cd0[p]);
+            for (int p = 0; p < P; ++p) {
+                Cheb ci = cheb_init(md, DI, din[p]);
 #pragma unroll
-            for (int k = 0; k < NX; ++k) aux[p][k] = 0.0;
+                for (int q = 0; q < JIN; ++q) {
+                    tab[p][q] = ci.cur;
+                    cheb_next(ci);
+                }
+                c0[p] = cheb_init(md, 0, dout[p]);
+            }
         }
         const int J0 = md.J[0];
         if constexpr (D == 2) {
@@ -230,23 +326,27 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
 #pragma unroll
-                    for (int k = 0; k < NX; ++k) aux[p][k] = PGAS_FMA(s0[p], in[p][k], aux[p][k]);
-                    rotate(s0[p], c0[p], sd0[p], cd0[p]);
+                    for (int k = 0; k < NX; ++k) aux[p][k] = PGAS_FMA(c0[p].cur, in[p][k], aux[p][k]);
+                    cheb_next(c0[p]);
                 }
             }
         } else {
-            double s1s[P], c1s[P], sd1[P], cd1[P];
+            Cheb c1s[P];
+            {
+                double r1[P];
+                DimStart d1[P];
 #pragma unroll
-            for (int p = 0; p < P; ++p) {
-                double r = PGAS_FMA(pick_input<NX>(md, 1, x[p], ut), md.alpha[1], md.beta[1]);
-                dim_start(md, 1, r, s1s[p], c1s[p], sd1[p], cd1[p]);
+                for (int p = 0; p < P; ++p) r1[p] = PGAS_FMA(pick_input<NX>(md, 1, x[p], ut), md.alpha[1], md.beta[1]);
+                dim_start_n<P>(md, 1, r1, d1);
+#pragma unroll
+                for (int p = 0; p < P; ++p) c1s[p] = cheb_init(md, 1, d1[p]);
             }
             const int J1 = md.J[1];
             for (int a = 0; a < J0; ++a) {
-                double mid[P][NX], s1[P], c1[P];
+                double mid[P][NX];
+                Cheb c1[P];
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
-                    s1[p] = s1s[p];
                     c1[p] = c1s[p];
 #pragma unroll
                     for (int k = 0; k < NX; ++k) mid[p][k] = 0.0;
@@ -270,17 +370,38 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
 #pragma unroll
-                        for (int k = 0; k < NX; ++k) mid[p][k] = PGAS_FMA(s1[p], in[p][k], mid[p][k]);
-                        rotate(s1[p], c1[p], sd1[p], cd1[p]);
+                        for (int k = 0; k < NX; ++k) mid[p][k] = PGAS_FMA(c1[p].cur, in[p][k], mid[p][k]);
+                        cheb_next(c1[p]);
                     }
                 }
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
 #pragma unroll
-                    for (int k = 0; k < NX; ++k) aux[p][k] = PGAS_FMA(s0[p], mid[p][k], aux[p][k]);
-                    rotate(s0[p], c0[p], sd0[p], cd0[p]);
+                    for (int k = 0; k < NX; ++k) aux[p][k] = PGAS_FMA(c0[p].cur, mid[p][k], aux[p][k]);
+                    cheb_next(c0[p]);
                 }
             }
+        }
+    }
+}
+
+// sines of every frequency of dimension d for ONE point (test hook / trajectory basis): s[q], q < J[d]
+template <int NX>
+__device__ __forceinline__ void dim_sines_point(const DevModel& md, int d, const double (&xv)[NX], const double* __restrict__ ut,
+                                                double* __restrict__ s) {
+    double r[1] = {PGAS_FMA(pick_input<NX>(md, d, xv, ut), md.alpha[d], md.beta[d])};
+    DimStart ds[1];
+    dim_start_n<1>(md, d, r, ds);
+    if (md.D == 1) {
+        for (int q = 0; q < md.J[d]; ++q) {
+            s[q] = ds[0].s0;
+            rotate(ds[0].s0, ds[0].c0, ds[0].sd, ds[0].cd);
+        }
+    } else {
+        Cheb c = cheb_init(md, d, ds[0]);
+        for (int q = 0; q < md.J[d]; ++q) {
+            s[q] = c.cur;
+            cheb_next(c);
         }
     }
 }
@@ -326,7 +447,7 @@ __global__ __launch_bounds__(PG_BLK) void k_init(DevModel md, uint64_t seed, con
 }
 
 // ------------------------------------------------------------------------------------------
-// segment softmax scan shared by k_front / k_fused / k_segscan.
+// segment softmax scan shared by k_front / k_resample / k_segscan.
 // lw[r] is the log-weight of particle seg*SEG + r*BLK + tid (-inf when past N).  Writes the
 // quantised inclusive cumsum (index order) and the segment (max, total).
 // ------------------------------------------------------------------------------------------
@@ -351,18 +472,26 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
         if (lane == 0) sm.red[w][wave] = m;
     }
     __syncthreads();
+    {
+        double arg[NW * PG_PPT], ev[NW * PG_PPT];
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        double m = sm.red[w][0];
+        for (int w = 0; w < NW; ++w) {
+            double m = sm.red[w][0];
 #pragma unroll
-        for (int v = 1; v < PG_BLK / 64; ++v) m = __builtin_fmax(m, sm.red[w][v]);
-        mx[w] = m;
+            for (int v = 1; v < PG_BLK / 64; ++v) m = __builtin_fmax(m, sm.red[w][v]);
+            mx[w] = m;
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
-            const double e = pgas_exp(lw[w][r] - m);
-            const uint64_t q = (e > 0.0) ? pgas_double_to_u64(__builtin_rint(e * PGAS_FIX_SCALE)) : 0ull;
-            sm.q[w][r * PG_BLK + tid] = q;
+            for (int r = 0; r < PG_PPT; ++r) arg[w * PG_PPT + r] = lw[w][r] - m;
         }
+        pgas_exp_n(arg, ev, NW * PG_PPT);
+#pragma unroll
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) {
+                const double e = ev[w * PG_PPT + r];
+                const uint64_t q = (e > 0.0) ? pgas_double_to_u64(__builtin_rint(e * PGAS_FIX_SCALE)) : 0ull;
+                sm.q[w][r * PG_BLK + tid] = q;
+            }
     }
     __syncthreads();
     uint64_t loc[NW][PG_PPT], incl[NW];
@@ -374,7 +503,7 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
             run += sm.q[w][PG_PPT * tid + j];
             loc[w][j] = run;
         }
-        incl[w] = wave_incl_scan_u64(run, lane);
+        incl[w] = wave_incl_scan_u64(run);
         if (lane == 63) sm.wtot[w][wave] = incl[w];
     }
     __syncthreads();
@@ -399,65 +528,106 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
 }
 
 // ------------------------------------------------------------------------------------------
-// front half of a step for the PG_PPT particles of this thread (src/PGAS.py:90-118,130-134)
+// per-particle part of a step for the PG_PPT particles of this thread (src/PGAS.py:90-100,109-116,130-134):
+//   la = log p(y_t | aux),  h = log N(ref_t; aux, S),  x_new = aux + L_S z  (conditioned particle = ref_t).
+// Reads only the particle's own state: in the reference the propagation does NOT depend on the
+// resampled ancestors (quirk Q1), which is what lets the sweep run this part for all time steps
+// without any synchronisation (k_propagate).
 // ------------------------------------------------------------------------------------------
 template <int NX, int D, int JIN, int P>
-__device__ __forceinline__ void front_particles(const DevModel& md, const TransParams& tp, int t, uint64_t seed,
-                                                const double* __restrict__ ref_t, int seg, const double (&xprev)[PG_PPT][NX],
-                                                const double (&logw)[PG_PPT], double* __restrict__ x_new,
-                                                double* __restrict__ laux_out, double (&lw)[2][PG_PPT]) {
+__device__ __forceinline__ void propagate_particles(const DevModel& md, const TransParams& tp, int t, uint64_t seed,
+                                                    const double* __restrict__ ref_t, int seg, const double (&xprev)[PG_PPT][NX],
+                                                    double (&xnew)[PG_PPT][NX], double (&la)[PG_PPT], double (&h)[PG_PPT]) {
     const int tid = threadIdx.x;
     const double* __restrict__ yt = md.y + (size_t)t * md.ny;
     const double* __restrict__ ut = md.u + (size_t)t * md.nu;
     double rf[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) rf[k] = ref_t[k];
+    double aux[PG_PPT][NX];
 #pragma unroll
     for (int r0 = 0; r0 < PG_PPT; r0 += P) {
-        double xin[P][NX], aux[P][NX];
+        double xin[P][NX], ax[P][NX];
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
             for (int k = 0; k < NX; ++k) xin[p][k] = xprev[r0 + p][k];
-        eval_mean<NX, D, JIN, P>(md, tp.G, ut, xin, aux);
+        eval_mean<NX, D, JIN, P>(md, tp.G, ut, xin, ax);
 #pragma unroll
-        for (int p = 0; p < P; ++p) {
-            const int r = r0 + p;
+        for (int p = 0; p < P; ++p)
+#pragma unroll
+            for (int k = 0; k < NX; ++k) aux[r0 + p][k] = ax[p][k];
+    }
+    // propagation noise for the four particles at once (Philox -> Box-Muller)
+    double z0[PG_PPT], z1[PG_PPT];
+    {
+        pgas_u32x4 w[PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
             const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-            const bool valid = pi < md.N;
-            const double la = loglik<NX>(md, yt, aux[p]);
-            const double l1 = la + logw[r];
-            double quad = 0.0;
-#pragma unroll
-            for (int k = 0; k < NX; ++k) {
-                double w = 0.0;
-#pragma unroll
-                for (int l = 0; l <= k; ++l) w = PGAS_FMA(tp.LSinv[k * NX + l], rf[l] - aux[p][l], w);
-                quad = PGAS_FMA(w, w, quad);
-            }
-            const double l2 = l1 + PGAS_FMA(-0.5, quad, tp.cS);
-            double z[2];
-            pgas_rng_normals(seed, PGAS_STREAM_PROP, (uint32_t)t, (uint64_t)pi, NX, z);
-            double xn[NX];
-#pragma unroll
-            for (int k = 0; k < NX; ++k) {
-                double v = aux[p][k];
-#pragma unroll
-                for (int l = 0; l <= k; ++l) v = PGAS_FMA(tp.LS[k * NX + l], z[l], v);
-                xn[k] = (pi == md.N - 1) ? rf[k] : v;
-            }
-            if (valid) {
-                if constexpr (NX == 2) {
-                    reinterpret_cast<double2*>(x_new)[pi] = make_double2(xn[0], xn[1]);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) x_new[pi * NX + k] = xn[k];
-                }
-                laux_out[pi] = la;
-            }
-            lw[0][r] = valid ? l1 : -__builtin_inf();
-            lw[1][r] = valid ? l2 : -__builtin_inf();
+            w[r] = pgas_rng_block(seed, PGAS_STREAM_PROP, 0u, (uint32_t)t, (uint64_t)pi);
         }
+        pgas_normal_pair_n(w, z0, z1, PG_PPT);
+    }
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) {
+        const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
+        la[r] = loglik<NX>(md, yt, aux[r]);
+        double quad = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            double w = 0.0;
+#pragma unroll
+            for (int l = 0; l <= k; ++l) w = PGAS_FMA(tp.LSinv[k * NX + l], rf[l] - aux[r][l], w);
+            quad = PGAS_FMA(w, w, quad);
+        }
+        h[r] = PGAS_FMA(-0.5, quad, tp.cS);
+        const double z[2] = {z0[r], z1[r]};
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            double v = aux[r][k];
+#pragma unroll
+            for (int l = 0; l <= k; ++l) v = PGAS_FMA(tp.LS[k * NX + l], z[l], v);
+            xnew[r][k] = (pi == md.N - 1) ? rf[k] : v;
+        }
+    }
+}
+
+template <int NX>
+__device__ __forceinline__ void store_particles(const DevModel& md, double* __restrict__ x, int seg, const double (&xv)[PG_PPT][NX]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) {
+        const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
+        if (pi < md.N) {
+            if constexpr (NX == 2) {
+                reinterpret_cast<double2*>(x)[pi] = make_double2(xv[r][0], xv[r][1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < NX; ++k) x[pi * NX + k] = xv[r][k];
+            }
+        }
+    }
+}
+
+// front half of one step as pgas_step needs it: propagate, store, log-weights of both softmaxes
+template <int NX, int D, int JIN, int P>
+__device__ __forceinline__ void front_particles(const DevModel& md, const TransParams& tp, int t, uint64_t seed,
+                                                const double* __restrict__ ref_t, int seg, const double (&xprev)[PG_PPT][NX],
+                                                const double (&logw)[PG_PPT], double* __restrict__ x_new,
+                                                double* __restrict__ laux_out, double (&lw)[2][PG_PPT]) {
+    const int tid = threadIdx.x;
+    double xn[PG_PPT][NX], la[PG_PPT], h[PG_PPT];
+    propagate_particles<NX, D, JIN, P>(md, tp, t, seed, ref_t, seg, xprev, xn, la, h);
+    store_particles<NX>(md, x_new, seg, xn);
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) {
+        const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
+        const bool valid = pi < md.N;
+        if (valid) laux_out[pi] = la[r];
+        const double l1 = la[r] + logw[r];
+        lw[0][r] = valid ? l1 : -__builtin_inf();
+        lw[1][r] = valid ? l1 + h[r] : -__builtin_inf();
     }
 }
 
@@ -503,171 +673,232 @@ __global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, TransParams tp, i
 // running maximum of the segment-end numerators and the normaliser S; block `search_block`
 // additionally counts #{k : W_k < u S} (ancestor of the reference particle, src/PGAS.py:121-124;
 // or the final index, :225).
+//
+// Latency is what matters here (one small workgroup per CDF on the sweep's critical path), so
+// the kernel is organised around few workgroup barriers: wave v owns the level-0 groups
+// g = v, v + 4, ... (64 consecutive segments each, Kogge-Stone by shuffles), the level-1/2 scans
+// are tiny and recomputed by every wave from LDS, and the running maximum needs one more barrier.
 // ------------------------------------------------------------------------------------------
-struct UpperSmem {                 // carved from dynamic LDS: inc[ninc] first (ninc = nseg rounded up to 1024)
-    double* inc;                  // level-0 inclusive values, later the running max cm
-    double* ga;                   // [PG_MAX_NSEG/64] level-0 group totals -> level-1 inclusive
-    double* gb;                   // [64] level-1 group totals -> level-2 inclusive
-    double* red;                  // [PG_UPPER_THREADS/64]
-    int* cnt;
+#define PG_UPPER_WAVES (PG_UPPER_THREADS / 64)
+#define PG_MAX_GROUPS (PG_MAX_NSEG / 64)
+template <int MG>  // capacity in level-0 groups
+struct UpperSmemT {
+    double ga[2][MG];                // level-0 group totals (up to two CDFs scanned together)
+    double gmax[2][MG];              // per-group maximum of the segment-end numerators
+    double red[2][PG_UPPER_WAVES];
+    double par[3];                   // (excl, scale, carry) of one segment, broadcast for cdf_count_block
+    int cnt[2];
 };
-static inline size_t upper_smem_bytes(int nseg) {
-    const size_t ninc = ((size_t)nseg + PG_UPPER_THREADS - 1) / PG_UPPER_THREADS * PG_UPPER_THREADS;
-    return (ninc + PG_MAX_NSEG / 64 + 64 + PG_UPPER_THREADS / 64) * sizeof(double) + 16;
+typedef UpperSmemT<PG_MAX_GROUPS> UpperSmem;
+
+// Cross-segment scan of NC (1 or 2) CDFs by a 256-thread workgroup, sharing the three workgroup barriers.
+// Thread (wave v, lane l) owns segments b = ((v + 4 e) << 6) + l, e < GPW, and gets their exclusive prefix, scale
+// and running maximum in registers; S[c] is the normaliser of CDF c.  CDF c reads segm/segs + c * stride.
+template <int GPW, int NC, class SM>  // level-0 groups (of 64 segments) per wave: nseg <= 64 * PG_UPPER_WAVES * GPW
+__device__ __forceinline__ void upper_core(SM& sm, const double* __restrict__ segm, const uint64_t* __restrict__ segs, int stride,
+                                           int nseg, double (&excl)[NC][GPW], double (&scale)[NC][GPW], double (&cmx)[NC][GPW],
+                                           double (&S)[NC]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n1 = (nseg + 63) >> 6;  // level-0 groups
+    const int n2 = (n1 + 63) >> 6;    // <= 2 for nseg <= 8192
+
+    // 1. global max of the segment maxima (group g of wave v: g = v + PG_UPPER_WAVES * e)
+    double mv[NC][GPW];
+    uint64_t sv[NC][GPW];
+    double g[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        g[c] = -__builtin_inf();
+#pragma unroll
+        for (int e = 0; e < GPW; ++e) {
+            const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
+            mv[c][e] = -__builtin_inf();
+            sv[c][e] = 0;
+            if (b < nseg) {
+                mv[c][e] = segm[(size_t)c * stride + b];
+                sv[c][e] = segs[(size_t)c * stride + b];
+            }
+            g[c] = __builtin_fmax(g[c], mv[c][e]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        g[c] = wave_max(g[c]);
+        if (lane == 0) sm.red[c][wave] = g[c];
+    }
+    if (tid < 2) sm.cnt[tid] = 0;
+    PG_STAMP(8);
+    __syncthreads();
+    PG_STAMP(9);
+    // 2. scaled totals and level-0 Kogge-Stone scans
+    double tot[NC][GPW], incA[NC][GPW];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        g[c] = sm.red[c][0];
+#pragma unroll
+        for (int v = 1; v < PG_UPPER_WAVES; ++v) g[c] = __builtin_fmax(g[c], sm.red[c][v]);
+        double arg[GPW], ev[GPW];
+#pragma unroll
+        for (int e = 0; e < GPW; ++e) arg[e] = mv[c][e] - g[c];
+        if constexpr (GPW <= PGAS_NB) {
+            pgas_exp_n(arg, ev, GPW);
+        } else {
+#pragma unroll
+            for (int e = 0; e < GPW; ++e) ev[e] = pgas_exp(arg[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < GPW; ++e) {
+            const int gi = wave + PG_UPPER_WAVES * e;
+            const int b = (gi << 6) + lane;
+            tot[c][e] = 0.0;
+            incA[c][e] = 0.0;
+            scale[c][e] = 0.0;
+            if (gi < n1) {  // wave-uniform
+                double sc = ev[e];
+                if (!(sc >= 0.0)) sc = 0.0;
+                if (b < nseg) {
+                    scale[c][e] = sc;
+                    tot[c][e] = sc * (pgas_u64_to_double(sv[c][e]) * PGAS_FIX_INV);
+                }
+                incA[c][e] = wave_scan_add(tot[c][e]);
+                if (lane == 63) sm.ga[c][gi] = incA[c][e];
+            }
+        }
+    }
+    PG_STAMP(10);
+    __syncthreads();
+    PG_STAMP(11);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        // 3. levels 1 and 2, recomputed by every wave: incB over the group totals (groups of 64), incC over those
+        double incB0 = wave_scan_add(lane < n1 ? sm.ga[c][lane] : 0.0);                            // level-1 group 0
+        double incB1 = n2 > 1 ? wave_scan_add(64 + lane < n1 ? sm.ga[c][64 + lane] : 0.0) : 0.0;   // level-1 group 1
+        const double GB0 = readlane_f64(incB0, 63);  // level 2 (zero padded): incC[0] = GB0
+        // 4. exclusive prefixes, segment-end numerators, per-group running maxima
+#pragma unroll
+        for (int e = 0; e < GPW; ++e) {
+            const int gi = wave + PG_UPPER_WAVES * e;
+            const int b = (gi << 6) + lane;
+            const int h = gi >> 6, l1 = gi & 63;
+            const double eC = h ? GB0 : 0.0;
+            const double srcB = h ? incB1 : incB0;
+            const double prevB = readlane_f64(srcB, l1 ? l1 - 1 : 0);
+            const double eB = l1 ? prevB : 0.0;
+            const double exB = eC + eB;
+            double wend = 0.0;
+            cmx[c][e] = 0.0;
+            excl[c][e] = 0.0;
+            if (gi < n1) {
+                const double up = __shfl_up(incA[c][e], 1);
+                const double eA = lane ? up : 0.0;
+                const double ex = exB + eA;
+                if (b < nseg) {
+                    excl[c][e] = ex;
+                    wend = ex + tot[c][e];
+                }
+                cmx[c][e] = wave_scan_max(wend);
+                if (lane == 63) sm.gmax[c][gi] = cmx[c][e];
+            }
+        }
+    }
+    PG_STAMP(12);
+    __syncthreads();
+    PG_STAMP(13);
+    // 5. running maximum across groups (exact, any order): carry of group gi = max of gmax[0..gi)
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        double m0 = wave_scan_max(lane < n1 ? sm.gmax[c][lane] : 0.0);
+        double m1 = n2 > 1 ? wave_scan_max(64 + lane < n1 ? sm.gmax[c][64 + lane] : 0.0) : 0.0;
+        const double M0 = readlane_f64(m0, 63), M1 = readlane_f64(m1, 63);
+#pragma unroll
+        for (int e = 0; e < GPW; ++e) {
+            const int gi = wave + PG_UPPER_WAVES * e;
+            if (gi < n1) {
+                const int h = gi >> 6, l1 = gi & 63;
+                const double src = h ? m1 : m0;
+                const double prev = readlane_f64(src, l1 ? l1 - 1 : 0);
+                double carry = l1 ? prev : 0.0;
+                if (h) carry = __builtin_fmax(carry, M0);
+                cmx[c][e] = __builtin_fmax(cmx[c][e], carry);
+            }
+        }
+        S[c] = __builtin_fmax(M0, M1);
+    }
 }
 
+// #{k : W_k < tau} for one CDF whose cross-segment scan sits in registers -- the searchsorted of
+// src/PGAS.py:122-124 / :225.  Three workgroup barriers; sm.cnt must be zero on entry (upper_core leaves it so).
+template <int GPW, class SM>
+__device__ __forceinline__ int cdf_count_block(SM& sm, const double (&ex)[GPW], const double (&sc)[GPW], const double (&cmx)[GPW],
+                                               int nseg, int N, double tau, const uint64_t* __restrict__ cbuf) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < GPW; ++e) {
+        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
+        c += (b < nseg && cmx[e] < tau) ? 1 : 0;
+    }
+    c = wave_sum_i(c);
+    if (lane == 0 && c) atomicAdd(&sm.cnt[0], c);
+    if (tid == 0) sm.par[2] = 0.0;
+    __syncthreads();
+    const int bs = sm.cnt[0];
+    if (bs >= nseg) return N - 1;
+#pragma unroll
+    for (int e = 0; e < GPW; ++e) {  // the owners of segments bs and bs-1 publish (excl, scale) and the carry
+        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
+        if (b == bs) {
+            sm.par[0] = ex[e];
+            sm.par[1] = sc[e];
+        }
+        if (b == bs - 1) sm.par[2] = cmx[e];
+    }
+    __syncthreads();
+    const int64_t base = (int64_t)bs * PGAS_SEG;
+    const int n = (N - base) < PGAS_SEG ? (int)(N - base) : PGAS_SEG;
+    const double e0 = sm.par[0], s0 = sm.par[1], cy = sm.par[2];
+    int k = 0;
+    for (int i = tid; i < n; i += PG_UPPER_THREADS) {
+        double num = e0 + s0 * (pgas_u64_to_double(cbuf[base + i]) * PGAS_FIX_INV);
+        num = __builtin_fmax(num, cy);
+        k += (num < tau) ? 1 : 0;
+    }
+    k = wave_sum_i(k);
+    if (lane == 0 && k) atomicAdd(&sm.cnt[1], k);
+    __syncthreads();
+    const int64_t r = base + sm.cnt[1];
+    return r > N - 1 ? N - 1 : (int)r;
+}
+
+template <int GPW>
 __global__ __launch_bounds__(PG_UPPER_THREADS) void k_upper(int N, int nseg, ScanBufs sb, int search_block, double u_search,
                                                              int final_mode) {
-    extern __shared__ __attribute__((aligned(16))) char upper_raw[];
+    __shared__ UpperSmem sm;
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    UpperSmem sm;
-    {
-        const size_t ninc = ((size_t)nseg + PG_UPPER_THREADS - 1) / PG_UPPER_THREADS * PG_UPPER_THREADS;
-        sm.inc = reinterpret_cast<double*>(upper_raw);
-        sm.ga = sm.inc + ninc;
-        sm.gb = sm.ga + PG_MAX_NSEG / 64;
-        sm.red = sm.gb + 64;
-        sm.cnt = reinterpret_cast<int*>(sm.red + PG_UPPER_THREADS / 64);
-    }
     const int nsegp = sb.nsegp;
-    const double* __restrict__ segm = sb.segm + (size_t)w * nsegp;
-    const uint64_t* __restrict__ segs = sb.segs + (size_t)w * nsegp;
     double* __restrict__ excl = sb.excl + (size_t)w * nsegp;
     double* __restrict__ scale = sb.scale + (size_t)w * nsegp;
     double* __restrict__ cm = sb.cm + (size_t)w * nsegp;
-    const int nchunk = (nseg + PG_UPPER_THREADS - 1) / PG_UPPER_THREADS;
-
-    // 1. global max of the segment maxima
-    double g = -__builtin_inf();
-    for (int b = tid; b < nseg; b += PG_UPPER_THREADS) g = __builtin_fmax(g, segm[b]);
-    g = wave_max(g);
-    if (lane == 0) sm.red[wave] = g;
-    if (tid == 0) *sm.cnt = 0;
-    __syncthreads();
-    g = sm.red[0];
-    for (int v = 1; v < PG_UPPER_THREADS / 64; ++v) g = __builtin_fmax(g, sm.red[v]);
-    __syncthreads();
-
-    // 2. scaled totals and level-0 scans (one wave = one group of 64 consecutive segments)
-    double tot[PG_MAX_NSEG / PG_UPPER_THREADS], incA[PG_MAX_NSEG / PG_UPPER_THREADS];
+    double ex[1][GPW], sc[1][GPW], cmx[1][GPW], Sv[1];
+    upper_core<GPW, 1>(sm, sb.segm + (size_t)w * nsegp, sb.segs + (size_t)w * nsegp, 0, nseg, ex, sc, cmx, Sv);
+    const double S = Sv[0];
 #pragma unroll
-    for (int e = 0; e < PG_MAX_NSEG / PG_UPPER_THREADS; ++e) {
-        tot[e] = 0.0;
-        incA[e] = 0.0;
-        if (e < nchunk) {
-            const int b = e * PG_UPPER_THREADS + tid;
-            if (b < nseg) {
-                double sc = pgas_exp(segm[b] - g);
-                if (!(sc >= 0.0)) sc = 0.0;
-                scale[b] = sc;
-                tot[e] = sc * (pgas_u64_to_double(segs[b]) * PGAS_FIX_INV);
-            }
-            incA[e] = wave_ks_add(tot[e], lane);
-            sm.inc[b] = incA[e];
-            if (lane == 63) sm.ga[b >> 6] = incA[e];
+    for (int e = 0; e < GPW; ++e) {
+        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
+        if (b < nseg) {
+            excl[b] = ex[0][e];
+            scale[b] = sc[0][e];
+            cm[b] = cmx[0][e];
         }
     }
-    __syncthreads();
-    // 3. level 1: groups of 64 level-0 totals
-    const int n1 = (nseg + 63) >> 6, n2 = (n1 + 63) >> 6;
-    if (wave < n2) {
-        const int gi = wave * 64 + lane;
-        double v = gi < n1 ? sm.ga[gi] : 0.0;
-        v = wave_ks_add(v, lane);
-        __builtin_amdgcn_wave_barrier();
-        sm.ga[gi] = v;  // ga is sized for n2*64 entries
-        if (lane == 63) sm.gb[wave] = v;
-    }
-    __syncthreads();
-    // 4. level 2
-    if (wave == 0) {
-        double v = lane < n2 ? sm.gb[lane] : 0.0;
-        v = wave_ks_add(v, lane);
-        sm.gb[lane] = v;
-    }
-    __syncthreads();
-    // 5. exclusive prefixes, segment-end numerators
-    double wend[PG_MAX_NSEG / PG_UPPER_THREADS];
-#pragma unroll
-    for (int e = 0; e < PG_MAX_NSEG / PG_UPPER_THREADS; ++e) {
-        wend[e] = 0.0;
-        if (e < nchunk) {
-            const int b = e * PG_UPPER_THREADS + tid;
-            const int gq = b >> 6, h = gq >> 6;
-            const double eC = (h & 63) ? sm.gb[h - 1] : 0.0;
-            const double eB = (gq & 63) ? sm.ga[gq - 1] : 0.0;
-            const double eA = (b & 63) ? sm.inc[b - 1] : 0.0;
-            const double ex = (eC + eB) + eA;
-            if (b < nseg) {
-                excl[b] = ex;
-                wend[e] = ex + tot[e];
-            }
-        }
-    }
-    __syncthreads();
-    // 6. running maximum of W_end (exact, any order)
-    double carry = 0.0;
-#pragma unroll
-    for (int e = 0; e < PG_MAX_NSEG / PG_UPPER_THREADS; ++e) {
-        if (e < nchunk) {  // uniform
-            const int b = e * PG_UPPER_THREADS + tid;
-            double v = wave_ks_max(wend[e], lane);
-            if (lane == 63) sm.red[wave] = v;
-            __syncthreads();
-            double pre = carry, all = carry;
-            for (int q = 0; q < PG_UPPER_THREADS / 64; ++q) {
-                const double tq = sm.red[q];
-                if (q < wave) pre = __builtin_fmax(pre, tq);
-                all = __builtin_fmax(all, tq);
-            }
-            v = __builtin_fmax(v, pre);
-            if (b < nseg) {
-                cm[b] = v;
-                sm.inc[b] = v;
-            }
-            carry = all;
-            __syncthreads();
-        }
-    }
-    const double S = carry;
     const bool valid = (S > 0.0) && (S < __builtin_inf());
     if (tid == 0) {
         sb.hdr->S[w] = S;
         sb.hdr->valid[w] = valid ? 1 : 0;
     }
     if (w != search_block) return;
-
-    // 7. #{k : W_k < tau}
     int result = N - 1;
-    if (valid) {
-        const double tau = u_search * S;
-        int c = 0;
-        for (int b = tid; b < nseg; b += PG_UPPER_THREADS) c += (sm.inc[b] < tau) ? 1 : 0;
-        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
-        if (lane == 0 && c) atomicAdd(sm.cnt, c);
-        __syncthreads();
-        const int bs = *sm.cnt;
-        __syncthreads();
-        if (bs < nseg) {
-            const int64_t base = (int64_t)bs * PGAS_SEG;
-            const int n = (N - base) < PGAS_SEG ? (int)(N - base) : PGAS_SEG;
-            const uint64_t* __restrict__ c = (w == 0 ? sb.c1 : sb.c2) + base;
-            const double ex = excl[bs], sc = scale[bs], cy = bs ? sm.inc[bs - 1] : 0.0;
-            if (tid == 0) *sm.cnt = 0;
-            __syncthreads();
-            int k = 0;
-            for (int i = tid; i < n; i += PG_UPPER_THREADS) {
-                double num = ex + sc * (pgas_u64_to_double(c[i]) * PGAS_FIX_INV);
-                num = __builtin_fmax(num, cy);
-                k += (num < tau) ? 1 : 0;
-            }
-            for (int off = 32; off >= 1; off >>= 1) k += __shfl_xor(k, off);
-            if (lane == 0 && k) atomicAdd(sm.cnt, k);
-            __syncthreads();
-            const int64_t r = base + *sm.cnt;
-            result = r > N - 1 ? N - 1 : (int)r;
-        }
-    }
+    if (valid) result = cdf_count_block<GPW>(sm, ex[0], sc[0], cmx[0], nseg, N, u_search * S, w == 0 ? sb.c1 : sb.c2);
     if (tid == 0) {
         if (final_mode)
             sb.hdr->final_idx = result;
@@ -678,107 +909,207 @@ __global__ __launch_bounds__(PG_UPPER_THREADS) void k_upper(int N, int nseg, Sca
 
 // ------------------------------------------------------------------------------------------
 // back half: systematic resampling search (src/Filtering.py:28-35) + weight update
-// (src/PGAS.py:137-147) for the PG_PPT slots of this thread.
+// (src/PGAS.py:137-147).
+//
+// Slot i = seg*SEG + 4*tid + j (four CONSECUTIVE slots per thread for the search; the thresholds
+// tau_i = U_i * S grow with i).  The workgroup finds the range of source segments its slots fall
+// into (two counts over the running-max array cm), stages the CDF numerators of up to
+// PG_STAGE segments at a time in LDS as doubles -- num_k = max(carry, excl + scale * c_k 2^-51),
+// evaluated once per source -- and every slot does a lower-bound search with plain double
+// compares.  Ancestors then go through LDS to the particle-major (strided) layout the front
+// half uses.
 // ------------------------------------------------------------------------------------------
+#define PG_STAGE 3
 struct BackSmem {
-    uint64_t c[PGAS_SEG];
-    int red[PG_BLK / 64];
+    double num[PG_STAGE][PGAS_SEG];
+    int a[PGAS_SEG];
+    int red[2][PG_BLK / 64];
 };
 
-// cmS: cm array of the resampling CDF staged in LDS (nseg doubles)
-template <int NX>
-__device__ __forceinline__ void back_slots(const DevModel& md, BackSmem& sm, const double* __restrict__ cmS, int t, double u1,
-                                           const ScanBufs& sb, int seg, const double (&xcur)[PG_PPT][NX], int32_t* __restrict__ anc_out,
-                                           double (&logw_new)[PG_PPT]) {
+// Resampling slot j of thread tid inside its workgroup's 1024 slots: lanes of a wave take consecutive slots (for every j),
+// so that the lower-bound probes of a wave fall on consecutive LDS words (no bank conflicts).
+__device__ __forceinline__ int slot_of(int tid, int j) { return ((tid >> 6) << 8) + (j << 6) + (tid & 63); }
+
+__device__ __forceinline__ double slot_tau(double u1, int64_t i, int N, double invN, bool pow2, double S) {
+    const double x = u1 + (double)i;
+    const double Ui = pow2 ? x * invN : x / (double)N;  // exact either way when N is a power of two
+    return Ui * S;
+}
+
+__device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm, double u1, const ScanBufs& sb, int seg,
+                                               int32_t* __restrict__ anc_out, int (&anc_pm)[PG_PPT]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nseg = md.nseg, N = md.N;
     const double S = sb.hdr->S[0];
     const bool valid = sb.hdr->valid[0] != 0;
+    const bool pow2 = (N & (N - 1)) == 0;
+    const double invN = 1.0 / (double)N;
+    const double* __restrict__ cm = sb.cm;
+    const int64_t base_i = (int64_t)seg * PGAS_SEG;
+    const int nslots = (N - base_i) < PGAS_SEG ? (int)(N - base_i) : PGAS_SEG;
+
     double tau[PG_PPT];
-    int bi[PG_PPT], a[PG_PPT];
+    int a[PG_PPT];
 #pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) {
-        const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-        const double Ui = (u1 + (double)i) / (double)N;
-        tau[r] = Ui * S;
-        // b_i = #{b : cm[b] < tau}
-        int lo = 0, hi = nseg;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (cmS[mid] < tau[r]) lo = mid + 1; else hi = mid;
-        }
-        bi[r] = (i < N && valid) ? lo : 0x7fffffff;
-        a[r] = (i < N) ? (valid ? N - 1 : (int)i) : 0;
+    for (int j = 0; j < PG_PPT; ++j) {
+        const int64_t i = base_i + slot_of(tid, j);
+        tau[j] = slot_tau(u1, i, N, invN, pow2, S);
+        a[j] = valid ? N - 1 : (int)(i < N ? i : N - 1);
     }
-    // visit the distinct segments referenced by this workgroup's slots in increasing order
-    int cur = -1;
-    while (true) {
-        int nxt = 0x7fffffff;
-#pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) nxt = (bi[r] > cur && bi[r] < nxt) ? bi[r] : nxt;
-        nxt = wave_min_i(nxt);
-        __syncthreads();  // previous iteration's readers are done with sm.c / sm.red
-        if (lane == 0) sm.red[wave] = nxt;
-        __syncthreads();
-        nxt = sm.red[0];
-#pragma unroll
-        for (int v = 1; v < PG_BLK / 64; ++v) nxt = sm.red[v] < nxt ? sm.red[v] : nxt;
-        if (nxt >= nseg) break;  // uniform: all remaining slots map past the last segment (a = N-1) or are done
-        cur = nxt;
-        const int64_t base = (int64_t)cur * PGAS_SEG;
-        const int n = (N - base) < PGAS_SEG ? (int)(N - base) : PGAS_SEG;
-        {
-            const ulonglong2* src = reinterpret_cast<const ulonglong2*>(sb.c1 + base);
-            ulonglong2* dst = reinterpret_cast<ulonglong2*>(sm.c);
-            dst[tid] = src[tid];
-            dst[tid + PG_BLK] = src[tid + PG_BLK];
+    if (valid) {  // uniform
+        // source-segment range of this workgroup: b_lo = #{b: cm[b] < tau_first}, b_hi = #{b: cm[b] < tau_last}
+        const double tau_first = slot_tau(u1, base_i, N, invN, pow2, S);
+        const double tau_last = slot_tau(u1, base_i + nslots - 1, N, invN, pow2, S);
+        int clo = 0, chi = 0;
+        for (int b = tid; b < nseg; b += PG_BLK) {
+            const double v = cm[b];
+            clo += (v < tau_first) ? 1 : 0;
+            chi += (v < tau_last) ? 1 : 0;
+        }
+        clo = wave_sum_i(clo);
+        chi = wave_sum_i(chi);
+        if (lane == 0) {
+            sm.red[0][wave] = clo;
+            sm.red[1][wave] = chi;
         }
         __syncthreads();
-        const double ex = sb.excl[cur], sc = sb.scale[cur], cy = cur ? cmS[cur - 1] : 0.0;
+        int b_lo = 0, b_hi = 0;
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
-            if (bi[r] == cur) {
-                int lo = 0, hi = n;
+        for (int v = 0; v < PG_BLK / 64; ++v) {
+            b_lo += sm.red[0][v];
+            b_hi += sm.red[1][v];
+        }
+        if (b_hi > nseg - 1) b_hi = nseg - 1;  // slots beyond the last segment keep a = N-1
+        // count the non-empty segments in [b_lo, b_hi] (empty ones -- running max unchanged -- own no slot)
+        int sb_idx[PG_STAGE];
+        double g_carry = 0.0;
+        int ns = 0, b = b_lo;
+        while (b <= b_hi && ns <= PG_STAGE) {
+            const double cy = b ? cm[b - 1] : 0.0, cb = cm[b];
+            if (cb > cy) {
+                if (ns == 0) g_carry = cy;
+                if (ns < PG_STAGE) sb_idx[ns] = b;
+                ++ns;
+            }
+            ++b;
+        }
+        if (ns > 0 && ns <= PG_STAGE) {
+            // ---- common case: the workgroup's slots fall into at most PG_STAGE source segments.  Stage their
+            // numerators back to back; they are non-decreasing across the whole window (running-max carry),
+            // so one branch-free lower-bound search per slot settles every slot.
+#pragma unroll
+            for (int g = 0; g < PG_STAGE; ++g) {
+                double4 v = make_double4(__builtin_inf(), __builtin_inf(), __builtin_inf(), __builtin_inf());
+                if (g < ns) {
+                    const int bs = sb_idx[g];
+                    const double ex = sb.excl[bs], sc = sb.scale[bs], cy = bs ? cm[bs - 1] : 0.0;
+                    const int64_t base_k = (int64_t)bs * PGAS_SEG;
+                    const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
+                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(sb.c1 + base_k) + 2 * tid;
+                    const ulonglong2 c01 = src[0], c23 = src[1];
+                    const int k0 = PG_PPT * tid;
+                    if (k0 + 0 < n) v.x = __builtin_fmax(ex + sc * (pgas_u64_to_double(c01.x) * PGAS_FIX_INV), cy);
+                    if (k0 + 1 < n) v.y = __builtin_fmax(ex + sc * (pgas_u64_to_double(c01.y) * PGAS_FIX_INV), cy);
+                    if (k0 + 2 < n) v.z = __builtin_fmax(ex + sc * (pgas_u64_to_double(c23.x) * PGAS_FIX_INV), cy);
+                    if (k0 + 3 < n) v.w = __builtin_fmax(ex + sc * (pgas_u64_to_double(c23.y) * PGAS_FIX_INV), cy);
+                }
+                reinterpret_cast<double4*>(sm.num[g])[tid] = v;
+            }
+            __syncthreads();
+            const double* __restrict__ num = &sm.num[0][0];
+            int pos[PG_PPT] = {0, 0, 0, 0};
+#pragma unroll
+            for (int step = 2048; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int j = 0; j < PG_PPT; ++j) {  // loads are unconditional so the four chains advance in lock step
+                    const int q = pos[j] + step;
+                    const int qc = q <= PG_STAGE * PGAS_SEG ? q : PG_STAGE * PGAS_SEG;
+                    const double v = num[qc - 1];
+                    pos[j] = (q <= PG_STAGE * PGAS_SEG && v < tau[j]) ? q : pos[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PG_PPT; ++j) {
+                if (g_carry < tau[j] && pos[j] < ns * PGAS_SEG) {
+                    const int g = pos[j] >> 10, off = pos[j] & (PGAS_SEG - 1);
+                    const int64_t ai = (int64_t)(g == 0 ? sb_idx[0] : g == 1 ? sb_idx[1] : sb_idx[2]) * PGAS_SEG + off;
+                    a[j] = ai > N - 1 ? N - 1 : (int)ai;
+                }
+            }
+        } else if (ns > PG_STAGE) {
+            // ---- degenerate weights: the slots of this workgroup spread over many source segments.  Staging them
+            // all would make this workgroup the straggler of the launch, so every slot searches for itself:
+            // segment by bisection over cm (global, cache resident), then bisection inside the segment.
+            int sbi[PG_PPT];
+#pragma unroll
+            for (int j = 0; j < PG_PPT; ++j) {
+                int lo = b_lo, hi = b_hi + 1;  // b_i = #{b : cm[b] < tau}
                 while (lo < hi) {
                     const int mid = (lo + hi) >> 1;
-                    double num = ex + sc * (pgas_u64_to_double(sm.c[mid]) * PGAS_FIX_INV);
-                    num = __builtin_fmax(num, cy);
-                    if (num < tau[r]) lo = mid + 1; else hi = mid;
+                    if (cm[mid] < tau[j]) lo = mid + 1; else hi = mid;
                 }
-                const int64_t ai = base + lo;
-                a[r] = ai > N - 1 ? N - 1 : (int)ai;
+                sbi[j] = lo;
+            }
+#pragma unroll
+            for (int j = 0; j < PG_PPT; ++j) {
+                const int bs = sbi[j];
+                if (bs < nseg) {
+                    const double ex = sb.excl[bs], sc = sb.scale[bs], cy = bs ? cm[bs - 1] : 0.0;
+                    const int64_t base_k = (int64_t)bs * PGAS_SEG;
+                    const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
+                    const uint64_t* __restrict__ c = sb.c1 + base_k;
+                    int lo = 0, hi = n;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const double v = __builtin_fmax(ex + sc * (pgas_u64_to_double(c[mid]) * PGAS_FIX_INV), cy);
+                        if (v < tau[j]) lo = mid + 1; else hi = mid;
+                    }
+                    const int64_t ai = base_k + lo;
+                    a[j] = ai > N - 1 ? N - 1 : (int)ai;
+                }
             }
         }
     }
+    // slot-major -> particle-major through LDS; the conditioned particle takes the ancestor drawn by k_upper
+#pragma unroll
+    for (int j = 0; j < PG_PPT; ++j) {
+        const int64_t i = base_i + slot_of(tid, j);
+        if (i == N - 1) a[j] = sb.hdr->ref_idx;  // src/PGAS.py:127
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PG_PPT; ++j) {
+        sm.a[slot_of(tid, j)] = a[j];
+        if (base_i + slot_of(tid, j) < N) anc_out[base_i + slot_of(tid, j)] = a[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) anc_pm[r] = sm.a[r * PG_BLK + tid];  // ancestor of particle base_i + r*BLK + tid
+}
+
+template <int NX>
+__device__ __forceinline__ void back_slots(const DevModel& md, BackSmem& sm, int t, double u1, const ScanBufs& sb, int seg,
+                                           const double (&xcur)[PG_PPT][NX], int32_t* __restrict__ anc_out, double (&logw_new)[PG_PPT]) {
+    const int tid = threadIdx.x;
+    int anc[PG_PPT];
+    resample_slots(md, sm, u1, sb, seg, anc_out, anc);
     const double* __restrict__ yt = md.y + (size_t)t * md.ny;
 #pragma unroll
     for (int r = 0; r < PG_PPT; ++r) {
         const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
         logw_new[r] = 0.0;
-        if (i < N) {
-            if (i == N - 1) a[r] = sb.hdr->ref_idx;  // src/PGAS.py:127
-            anc_out[i] = a[r];
-            logw_new[r] = loglik<NX>(md, yt, xcur[r]) - sb.laux[a[r]];
-        }
+        if (i < md.N) logw_new[r] = loglik<NX>(md, yt, xcur[r]) - sb.laux[anc[r]];
     }
-}
-
-__device__ __forceinline__ void stage_cm(double* cmS, const double* __restrict__ cm, int nseg) {
-    for (int b = threadIdx.x; b < nseg; b += PG_BLK) cmS[b] = cm[b];
-    __syncthreads();
 }
 
 template <int NX>
 __global__ __launch_bounds__(PG_BLK) void k_back(DevModel md, int t, double u1, const double* __restrict__ x_cur, ScanBufs sb,
                                                   int32_t* __restrict__ anc_out, double* __restrict__ logw_out) {
     __shared__ BackSmem sm;
-    extern __shared__ __attribute__((aligned(16))) char dyn_raw[];
-    double* cmS = reinterpret_cast<double*>(dyn_raw);
     const int seg = blockIdx.x, tid = threadIdx.x;
-    stage_cm(cmS, sb.cm, md.nseg);
     double xv[PG_PPT][NX], lwn[PG_PPT];
     load_particles<NX>(md, x_cur, seg, xv);
-    back_slots<NX>(md, sm, cmS, t, u1, sb, seg, xv, anc_out, lwn);
+    back_slots<NX>(md, sm, t, u1, sb, seg, xv, anc_out, lwn);
 #pragma unroll
     for (int r = 0; r < PG_PPT; ++r) {
         const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
@@ -787,36 +1118,382 @@ __global__ __launch_bounds__(PG_BLK) void k_back(DevModel md, int t, double u1, 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_fused: back half of step t-1 followed by the front half of step t for the same particles
-// (the log-weight never leaves registers).  sb_prev holds step t-1's scan results, sb_next
-// receives step t's.
+// The sweep (condSequentialMonteCarlo.__call__, src/PGAS.py:176-228) as two decoupled pipelines.
+//
+// k_propagate  advances every particle through time steps [t0, t1) with its state in registers:
+//              no dependence on the weights or ancestors (quirk Q1), hence no barrier, no LDS, no
+//              inter-workgroup traffic.  Per particle-step it writes x_t (trace), la_t = log p(y_t|aux_t),
+//              h_t = log N(ref_t; aux_t, S) and ln_t = log p(y_t | x_t): everything the weight
+//              recursion needs later.
+// k_resample   one launch per time step: systematic-resampling search of step t-1 (needs k_upper(t-1)),
+//              logw_{t-1} = ln_{t-1} - la_{t-1}[a], then both softmax scans of step t.
 // ------------------------------------------------------------------------------------------
-template <int NX, int D, int JIN, int P>
-__global__ __launch_bounds__(PG_BLK) void k_fused(DevModel md, TransParams tp, int t, uint64_t seed, double u1_prev,
-                                                   const double* __restrict__ x_prev, const double* __restrict__ ref_t,
-                                                   double* __restrict__ x_new, ScanBufs sb_prev, ScanBufs sb_next,
-                                                   int32_t* __restrict__ anc_out, double* __restrict__ logw_trace_row) {
+template <int NX, int D, int JIN, int P, int W>
+__global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParams tp, uint64_t seed, int t0, int t1,
+                                                          double* __restrict__ x_trace, const double* __restrict__ ref,
+                                                          double* __restrict__ la_buf, double* __restrict__ h_buf,
+                                                          double* __restrict__ ln_buf) {
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    const size_t row = (size_t)md.N * NX, np = (size_t)md.nseg * PGAS_SEG;
+    double xv[PG_PPT][NX];
+    load_particles<NX>(md, x_trace + (size_t)(t0 - 1) * row, seg, xv);
+    for (int t = t0; t < t1; ++t) {
+        double xn[PG_PPT][NX], la[PG_PPT], h[PG_PPT];
+        propagate_particles<NX, D, JIN, P>(md, tp, t, seed, ref + (size_t)t * NX, seg, xv, xn, la, h);
+        store_particles<NX>(md, x_trace + (size_t)t * row, seg, xn);
+        const double* __restrict__ yt = md.y + (size_t)t * md.ny;
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            const size_t pi = (size_t)seg * PGAS_SEG + r * PG_BLK + tid;  // buffers are padded to nseg*SEG
+            la_buf[(size_t)t * np + pi] = la[r];
+            h_buf[(size_t)t * np + pi] = h[r];
+            ln_buf[(size_t)t * np + pi] = loglik<NX>(md, yt, xn[r]);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xv[r][k] = xn[r][k];
+        }
+    }
+}
+
+// mode bits of k_resample
+#define PG_RS_SEARCH 1  // resample step t-1 (sb_prev valid) and form logw_{t-1}; otherwise logw_{t-1} = 0 (t = 1)
+#define PG_RS_SCAN 2    // scan step t's weights into sb_next; otherwise only emit logw_{t-1} (after the last step)
+__global__ __launch_bounds__(PG_BLK) void k_resample(DevModel md, int t, int mode, double u1_prev, const double* __restrict__ la_t,
+                                                      const double* __restrict__ h_t, const double* __restrict__ ln_prev,
+                                                      ScanBufs sb_prev, ScanBufs sb_next, int32_t* __restrict__ anc_out,
+                                                      double* __restrict__ logw_out) {
     __shared__ union {
         BackSmem b;
         ScanSmem s;
     } sm;
-    extern __shared__ __attribute__((aligned(16))) char dyn_raw[];
-    double* cmS = reinterpret_cast<double*>(dyn_raw);
     const int seg = blockIdx.x, tid = threadIdx.x;
-    stage_cm(cmS, sb_prev.cm, md.nseg);
-    double xv[PG_PPT][NX], lwp[PG_PPT], lw[2][PG_PPT];
-    load_particles<NX>(md, x_prev, seg, xv);
-    back_slots<NX>(md, sm.b, cmS, t - 1, u1_prev, sb_prev, seg, xv, anc_out, lwp);
-    if (logw_trace_row != nullptr) {
+    double lwp[PG_PPT] = {0.0, 0.0, 0.0, 0.0};
+    if (mode & PG_RS_SEARCH) {
+        double lnv[PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) lnv[r] = ln_prev[(size_t)seg * PGAS_SEG + r * PG_BLK + tid];
+        int anc[PG_PPT];
+        resample_slots(md, sm.b, u1_prev, sb_prev, seg, anc_out, anc);
 #pragma unroll
         for (int r = 0; r < PG_PPT; ++r) {
             const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-            if (i < md.N) logw_trace_row[i] = lwp[r];
+            if (i < md.N) lwp[r] = lnv[r] - sb_prev.laux[anc[r]];
         }
+        if (logw_out != nullptr) {
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) {
+                const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
+                if (i < md.N) logw_out[i] = lwp[r];
+            }
+        }
+        __syncthreads();  // BackSmem -> ScanSmem reuse
     }
-    front_particles<NX, D, JIN, P>(md, tp, t, seed, ref_t, seg, xv, lwp, x_new, sb_next.laux, lw);
-    __syncthreads();  // BackSmem -> ScanSmem reuse
-    segment_scan<2>(sm.s, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm, sb_next.segs);
+    if (mode & PG_RS_SCAN) {
+        double lw[2][PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            const size_t pi = (size_t)seg * PGAS_SEG + r * PG_BLK + tid;
+            const bool valid = pi < (size_t)md.N;
+            const double l1 = la_t[pi] + lwp[r];
+            lw[0][r] = valid ? l1 : -__builtin_inf();
+            lw[1][r] = valid ? l1 + h_t[pi] : -__builtin_inf();
+        }
+        segment_scan<2>(sm.s, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm, sb_next.segs);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_resample_fast: k_resample with the cross-segment scan of step t-1 folded in (no k_upper launch on
+// the critical path).  Every workgroup recomputes the scan of the resampling CDF from the nseg <= 1024
+// segment (max,total) pairs -- 16 KB from L2, three barriers -- keeps its running maximum in LDS, and goes
+// straight on to the search.  The workgroup that owns the conditioned particle N-1 also scans the
+// ancestor CDF and draws the reference particle's ancestor (src/PGAS.py:121-127).  Bit-identical to the
+// k_upper + k_resample pair (same upper_core, same search).
+// ------------------------------------------------------------------------------------------
+#define PG_FAST_GPW 4
+#define PG_FGROUPS 4  // at most this many staged windows per workgroup before falling back to per-slot bisection
+#define PG_FSTAGE 2   // source segments staged at once by k_resample_fast (LDS budget: five workgroups per CU)
+#define PG_FAST_NSEG (64 * PG_UPPER_WAVES * PG_FAST_GPW)
+struct FastSmem {
+    double cm[PG_FAST_NSEG];
+    union {
+        double num[PG_FSTAGE][PGAS_SEG];
+        struct {
+            double excl[PG_FAST_NSEG], scale[PG_FAST_NSEG];
+        } tab;
+        ScanSmem scan;
+    } u;
+    int a[PGAS_SEG];
+    // candidate source segments of this workgroup (index, excl, scale, carry): copied out of `tab` before staging reuses it
+    int cand_b[PG_FGROUPS * PG_FSTAGE];
+    double cand_ex[PG_FGROUPS * PG_FSTAGE], cand_sc[PG_FGROUPS * PG_FSTAGE], cand_cy[PG_FGROUPS * PG_FSTAGE];
+    UpperSmemT<PG_UPPER_WAVES * PG_FAST_GPW> up;
+};
+
+// Grid = nseg + 1 workgroups.  Workgroup 0 only draws the reference particle's ancestor (scan of the ancestor CDF + one
+// count, src/PGAS.py:121-127) and publishes it as one 8-byte {launch tag, index} word; workgroup b + 1 owns segment b.
+// The workgroup that owns the conditioned particle reads that word late (after its own search).  Workgroup 0 never
+// waits for anyone, so the hand-off cannot deadlock whatever the dispatch order; if the word has not arrived within the
+// spin budget the owner computes the ancestor itself (same code, same result).
+__global__ __launch_bounds__(PG_BLK, 5) void k_resample_fast(DevModel md, int t, int mode, unsigned tag, double u1_prev, double u2_prev,
+                                                           const double* __restrict__ la_t, const double* __restrict__ h_t,
+                                                           const double* __restrict__ ln_prev, ScanBufs sb_prev, ScanBufs sb_next,
+                                                           int32_t* __restrict__ anc_out, double* __restrict__ logw_out) {
+    __shared__ FastSmem sm;
+    constexpr int GPW = PG_FAST_GPW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int nseg = md.nseg, N = md.N;
+    if (blockIdx.x == 0) {  // ---- ancestor workgroup
+        if (!(mode & PG_RS_SEARCH)) return;
+        double ex2[1][GPW], sc2[1][GPW], cm2[1][GPW], S2[1];
+        upper_core<GPW, 1>(sm.up, sb_prev.segm + sb_prev.nsegp, sb_prev.segs + sb_prev.nsegp, 0, nseg, ex2, sc2, cm2, S2);
+        int r = N - 1;
+        if ((S2[0] > 0.0) && (S2[0] < __builtin_inf()))
+            r = cdf_count_block<GPW>(sm.up, ex2[0], sc2[0], cm2[0], nseg, N, u2_prev * S2[0], sb_prev.c2);
+        if (tid == 0)
+            __hip_atomic_store(&sb_prev.hdr->ref_granule, ((unsigned long long)tag << 32) | (unsigned)r, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int seg = blockIdx.x - 1;
+    const int64_t base_i = (int64_t)seg * PGAS_SEG;
+    PG_STAMP(0);
+    // own-particle inputs first: their latency overlaps the scan below
+    double lnv[PG_PPT];
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) lnv[r] = (mode & PG_RS_SEARCH) ? ln_prev[(size_t)base_i + r * PG_BLK + tid] : 0.0;
+    double lwp[PG_PPT] = {0.0, 0.0, 0.0, 0.0};
+    if (mode & PG_RS_SEARCH) {
+        const int nsegp = sb_prev.nsegp;
+        // ---- cross-segment scan of the resampling CDF of step t-1; the workgroup that owns the conditioned particle
+        // scans the ancestor CDF in the same pass (shared barriers) and draws the reference particle's ancestor
+        // (src/PGAS.py:121-127)
+        const bool last_wg = base_i + PGAS_SEG >= N;  // uniform
+        double ex[GPW], sc[GPW], cmx[GPW], S;
+        {
+            double ex1[1][GPW], sc1[1][GPW], cm1[1][GPW], S1[1];
+            upper_core<GPW, 1>(sm.up, sb_prev.segm, sb_prev.segs, 0, nseg, ex1, sc1, cm1, S1);
+#pragma unroll
+            for (int e = 0; e < GPW; ++e) {
+                ex[e] = ex1[0][e];
+                sc[e] = sc1[0][e];
+                cmx[e] = cm1[0][e];
+            }
+            S = S1[0];
+        }
+        const bool valid = (S > 0.0) && (S < __builtin_inf());
+        PG_STAMP(1);
+#pragma unroll
+        for (int e = 0; e < GPW; ++e) {
+            const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
+            sm.cm[b] = b < nseg ? cmx[e] : __builtin_inf();
+            sm.u.tab.excl[b] = ex[e];
+            sm.u.tab.scale[b] = sc[e];
+        }
+        __syncthreads();
+        const bool pow2 = (N & (N - 1)) == 0;
+        const double invN = 1.0 / (double)N;
+        const int nslots = (N - base_i) < PGAS_SEG ? (int)(N - base_i) : PGAS_SEG;
+        double tau[PG_PPT];
+        int a[PG_PPT];
+#pragma unroll
+        for (int j = 0; j < PG_PPT; ++j) {
+            const int64_t i = base_i + slot_of(tid, j);
+            tau[j] = slot_tau(u1_prev, i, N, invN, pow2, S);
+            a[j] = valid ? N - 1 : (int)(i < N ? i : N - 1);
+        }
+        int ns = 0;  // non-empty source segments in [b_lo, b_hi], counted up to PG_FGROUPS * PG_FSTAGE + 1
+        int b_lo = 0, b_hi = 0;
+        if (valid) {  // uniform
+            // source-segment range of this workgroup: lower bounds over the running maxima (branch-free bisection, LDS)
+            const double tau_first = slot_tau(u1_prev, base_i, N, invN, pow2, S);
+            const double tau_last = slot_tau(u1_prev, base_i + nslots - 1, N, invN, pow2, S);
+#pragma unroll
+            for (int step = PG_FAST_NSEG / 2; step >= 1; step >>= 1) {
+                if (sm.cm[b_lo + step - 1] < tau_first) b_lo += step;
+                if (sm.cm[b_hi + step - 1] < tau_last) b_hi += step;
+            }
+            // (cm is padded with +inf, so both counts are <= nseg; a count of nseg means "past the last segment")
+            if (b_hi > nseg - 1) b_hi = nseg - 1;
+            // enumerate the non-empty source segments of [b_lo, b_hi] (a segment whose running max did not move owns no
+            // slot) by bisection jumps: the next one after carry c is #{b : cm[b] <= c}.  Bounded work however long the
+            // run of empty segments between two heavy particles is.
+            int b = b_lo;
+            while (ns <= PG_FGROUPS * PG_FSTAGE) {
+                const double c0 = b ? sm.cm[b - 1] : 0.0;
+                int nb = 0;
+#pragma unroll
+                for (int step = PG_FAST_NSEG / 2; step >= 1; step >>= 1)
+                    if (sm.cm[nb + step - 1] <= c0) nb += step;
+                if (nb + 1 <= PG_FAST_NSEG && sm.cm[nb] <= c0) ++nb;  // all PG_FAST_NSEG entries <= c0 cannot happen (cm pads with +inf or ends at S > c0)
+                if (nb > b_hi) break;
+                if (ns < PG_FGROUPS * PG_FSTAGE && tid == 0) {
+                    sm.cand_b[ns] = nb;
+                    sm.cand_ex[ns] = sm.u.tab.excl[nb];
+                    sm.cand_sc[ns] = sm.u.tab.scale[nb];
+                    sm.cand_cy[ns] = c0;
+                }
+                ++ns;
+                b = nb + 1;
+            }
+        }
+        PG_STAMP(2);
+        if (ns > 0 && ns <= PG_FGROUPS * PG_FSTAGE) {
+            // ---- common case: stage the numerators of PG_FSTAGE source segments at a time, back to back; they are
+            // non-decreasing across the window (running-max carry), so one branch-free lower bound per slot settles
+            // every slot that falls into the window
+            __syncthreads();
+            for (int k0w = 0; k0w < ns; k0w += PG_FSTAGE) {  // uniform
+                const int ng = ns - k0w < PG_FSTAGE ? ns - k0w : PG_FSTAGE;
+                int sb_idx[PG_FSTAGE] = {0, 0};
+                double sex[PG_FSTAGE] = {0.0, 0.0}, ssc[PG_FSTAGE] = {0.0, 0.0}, scy[PG_FSTAGE] = {0.0, 0.0};
+#pragma unroll
+                for (int g = 0; g < PG_FSTAGE; ++g) {
+                    if (g < ng) {
+                        sb_idx[g] = sm.cand_b[k0w + g];
+                        sex[g] = sm.cand_ex[k0w + g];
+                        ssc[g] = sm.cand_sc[k0w + g];
+                        scy[g] = sm.cand_cy[k0w + g];
+                    }
+                }
+                const double g_carry = scy[0];
+                // global loads first, then the barrier that frees the table / the previous window
+                ulonglong2 c01[PG_FSTAGE], c23[PG_FSTAGE];
+#pragma unroll
+                for (int g = 0; g < PG_FSTAGE; ++g) {
+                    if (g < ng) {
+                        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(sb_prev.c1 + (int64_t)sb_idx[g] * PGAS_SEG) + 2 * tid;
+                        c01[g] = src[0];
+                        c23[g] = src[1];
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int g = 0; g < PG_FSTAGE; ++g) {
+                    double4 v = make_double4(__builtin_inf(), __builtin_inf(), __builtin_inf(), __builtin_inf());
+                    if (g < ng) {
+                        const int64_t base_k = (int64_t)sb_idx[g] * PGAS_SEG;
+                        const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
+                        const int k0 = PG_PPT * tid;
+                        const double e0 = sex[g], s0 = ssc[g], cy = scy[g];
+                        if (k0 + 0 < n) v.x = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c01[g].x) * PGAS_FIX_INV), cy);
+                        if (k0 + 1 < n) v.y = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c01[g].y) * PGAS_FIX_INV), cy);
+                        if (k0 + 2 < n) v.z = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c23[g].x) * PGAS_FIX_INV), cy);
+                        if (k0 + 3 < n) v.w = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c23[g].y) * PGAS_FIX_INV), cy);
+                    }
+                    reinterpret_cast<double4*>(sm.u.num[g])[tid] = v;
+                }
+                __syncthreads();
+                PG_STAMP(3);
+                const double* __restrict__ num = &sm.u.num[0][0];
+                int pos[PG_PPT] = {0, 0, 0, 0};
+#pragma unroll
+                for (int step = PG_FSTAGE * PGAS_SEG / 2; step >= 1; step >>= 1) {
+#pragma unroll
+                    for (int j = 0; j < PG_PPT; ++j) {  // loads are unconditional so the four chains advance in lock step
+                        const int q = pos[j] + step;
+                        const int qc = q <= PG_FSTAGE * PGAS_SEG ? q : PG_FSTAGE * PGAS_SEG;
+                        const double v = num[qc - 1];
+                        pos[j] = (q <= PG_FSTAGE * PGAS_SEG && v < tau[j]) ? q : pos[j];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < PG_PPT; ++j) {
+                    if (g_carry < tau[j] && pos[j] < ng * PGAS_SEG) {
+                        const int g = pos[j] >> 10, off = pos[j] & (PGAS_SEG - 1);
+                        const int64_t ai = (int64_t)(g == 0 ? sb_idx[0] : sb_idx[1]) * PGAS_SEG + off;
+                        a[j] = ai > N - 1 ? N - 1 : (int)ai;
+                    }
+                }
+            }
+        } else if (ns > PG_FGROUPS * PG_FSTAGE) {
+            // degenerate weights: per-slot bisection, segment level in LDS, particle level in global memory
+#pragma unroll
+            for (int j = 0; j < PG_PPT; ++j) {
+                int bs = 0;
+#pragma unroll
+                for (int step = PG_FAST_NSEG / 2; step >= 1; step >>= 1)
+                    if (sm.cm[bs + step - 1] < tau[j]) bs += step;
+                if (bs < nseg) {
+                    const double e0 = sm.u.tab.excl[bs], s0 = sm.u.tab.scale[bs], cy = bs ? sm.cm[bs - 1] : 0.0;
+                    const int64_t base_k = (int64_t)bs * PGAS_SEG;
+                    const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
+                    const uint64_t* __restrict__ c = sb_prev.c1 + base_k;
+                    int lo = 0, hi = n;
+                    while (lo < hi) {
+                        const int mid = (lo + hi) >> 1;
+                        const double v = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c[mid]) * PGAS_FIX_INV), cy);
+                        if (v < tau[j]) lo = mid + 1; else hi = mid;
+                    }
+                    const int64_t ai = base_k + lo;
+                    a[j] = ai > N - 1 ? N - 1 : (int)ai;
+                }
+            }
+        }
+        if (last_wg) {
+            // ancestor of the conditioned particle, published by workgroup 0 (src/PGAS.py:127)
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long g = 0;
+                int spins = 0;
+                for (; spins < (1 << 16); ++spins) {
+                    g = __hip_atomic_load(&sb_prev.hdr->ref_granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(g >> 32) == tag) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                sm.up.cnt[0] = ((unsigned)(g >> 32) == tag) ? (int)(unsigned)g : -1;
+            }
+            __syncthreads();
+            int ref_idx = sm.up.cnt[0];
+            if (ref_idx < 0) {  // uniform: the word never arrived -- draw the ancestor here
+                __syncthreads();
+                double ex2[1][GPW], sc2[1][GPW], cm2[1][GPW], S2[1];
+                upper_core<GPW, 1>(sm.up, sb_prev.segm + nsegp, sb_prev.segs + nsegp, 0, nseg, ex2, sc2, cm2, S2);
+                ref_idx = N - 1;
+                if ((S2[0] > 0.0) && (S2[0] < __builtin_inf()))
+                    ref_idx = cdf_count_block<GPW>(sm.up, ex2[0], sc2[0], cm2[0], nseg, N, u2_prev * S2[0], sb_prev.c2);
+            }
+#pragma unroll
+            for (int j = 0; j < PG_PPT; ++j)
+                if (base_i + slot_of(tid, j) == N - 1) a[j] = ref_idx;
+        }
+        PG_STAMP(4);
+        // ---- slot-major -> particle-major through LDS, ancestor trace, weight update
+        __syncthreads();
+    #pragma unroll
+        for (int j = 0; j < PG_PPT; ++j) {
+            sm.a[slot_of(tid, j)] = a[j];
+            if (base_i + slot_of(tid, j) < N) anc_out[base_i + slot_of(tid, j)] = a[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            const int64_t i = base_i + r * PG_BLK + tid;
+            if (i < N) lwp[r] = lnv[r] - sb_prev.laux[sm.a[r * PG_BLK + tid]];
+        }
+        PG_STAMP(5);
+        if (logw_out != nullptr) {
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) {
+                const int64_t i = base_i + r * PG_BLK + tid;
+                if (i < N) logw_out[i] = lwp[r];
+            }
+        }
+        __syncthreads();  // staging area -> ScanSmem reuse
+    }
+    if (mode & PG_RS_SCAN) {
+        double lw[2][PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            const size_t pi = (size_t)base_i + r * PG_BLK + tid;
+            const bool valid_p = pi < (size_t)N;
+            const double l1 = la_t[pi] + lwp[r];
+            lw[0][r] = valid_p ? l1 : -__builtin_inf();
+            lw[1][r] = valid_p ? l1 + h_t[pi] : -__builtin_inf();
+        }
+        PG_STAMP(6);
+        segment_scan<2>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm, sb_next.segs);
+    }
+    PG_STAMP(7);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -860,19 +1537,11 @@ __global__ __launch_bounds__(PG_BLK) void k_basis_eval(DevModel md, const int32_
     double xv[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) xv[k] = x[p * NX + k];
-    double sc[PGAS_MAX_D], cc[PGAS_MAX_D], sd[PGAS_MAX_D], cd[PGAS_MAX_D];
-    for (int d = 0; d < md.D; ++d) {
-        const double r = PGAS_FMA(pick_input<NX>(md, d, xv, ut), md.alpha[d], md.beta[d]);
-        dim_start(md, d, r, sc[d], cc[d], sd[d], cd[d]);
-    }
+    double sv[PGAS_MAX_D][PGAS_MAX_J];
+    for (int d = 0; d < md.D; ++d) dim_sines_point<NX>(md, d, xv, ut, sv[d]);
     for (int m = 0; m < md.M; ++m) {
         double f = md.nrm;
-        for (int d = 0; d < md.D; ++d) {
-            const int q = (idx[m * md.D + d] - md.j0[d]) / md.jstep[d];
-            double s = sc[d], c = cc[d];
-            for (int i = 0; i < q; ++i) rotate(s, c, sd[d], cd[d]);
-            f = f * s;
-        }
+        for (int d = 0; d < md.D; ++d) f = f * sv[d][(idx[m * md.D + d] - md.j0[d]) / md.jstep[d]];
         phi[p * md.M + m] = f;
     }
 }

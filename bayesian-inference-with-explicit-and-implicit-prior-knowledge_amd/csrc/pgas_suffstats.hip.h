@@ -20,19 +20,11 @@ __global__ __launch_bounds__(64) void k_traj_basis(DevModel md, const int32_t* _
     double xv[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) xv[k] = traj[(size_t)r * NX + k];
-    double sc[PGAS_MAX_D], cc[PGAS_MAX_D], sd[PGAS_MAX_D], cd[PGAS_MAX_D];
-    for (int d = 0; d < md.D; ++d) {
-        const double rr = PGAS_FMA(pick_input<NX>(md, d, xv, ut), md.alpha[d], md.beta[d]);
-        dim_start(md, d, rr, sc[d], cc[d], sd[d], cd[d]);
-    }
+    double sv[PGAS_MAX_D][PGAS_MAX_J];
+    for (int d = 0; d < md.D; ++d) dim_sines_point<NX>(md, d, xv, ut, sv[d]);
     for (int m = 0; m < md.M; ++m) {
         double f = md.nrm;
-        for (int d = 0; d < md.D; ++d) {
-            const int q = (idx[m * md.D + d] - md.j0[d]) / md.jstep[d];
-            double s = sc[d], c = cc[d];
-            for (int i = 0; i < q; ++i) rotate(s, c, sd[d], cd[d]);
-            f = f * s;
-        }
+        for (int d = 0; d < md.D; ++d) f = f * sv[d][(idx[m * md.D + d] - md.j0[d]) / md.jstep[d]];
         phi[(size_t)r * Mp + m] = f;
     }
 }

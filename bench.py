@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--T", type=int, default=2000)
     ap.add_argument("--cpu-steps", type=int, default=20, help="steps of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--chunk", type=int, default=-1, help="time steps per k_propagate launch (engine default if < 0)")
+    ap.add_argument("--no-overlap", action="store_true", help="run the weight recursion on the caller's stream (no concurrency)")
     args = ap.parse_args()
 
     import torch
@@ -89,6 +91,10 @@ def main():
     # (A, S) from one sample_params on the initial reference trajectory
     A, S = pg.sample_params(pgas_amd.random.key(seed), ref)
     eng.set_profiling(not args.no_profile)
+    if args.chunk >= 0:
+        eng.set_option(1, args.chunk)      # PGAS_OPT_PROPAGATE_CHUNK
+    if args.no_overlap:
+        eng.set_option(3, 0)               # PGAS_OPT_OVERLAP
 
     def barrier():
         if world > 1:
@@ -99,13 +105,14 @@ def main():
         pg.cSMC(seed + 1000 + w, ref, A, S)
     barrier()
     t0 = time.perf_counter()
-    prof_n, prof_ms = 0, 0.0
+    prof_n, prof_ms, prop_ms = 0, 0.0, 0.0
     for k in range(args.steps):
         pg.cSMC(seed + k, ref, A, S)
         if not args.no_profile:
-            n, ms = eng.profile()   # synchronises this sweep; the events sit inside the timed region
+            n, ms, pm = eng.profile()   # synchronises this sweep; the events sit inside the timed region
             prof_n += n
             prof_ms += ms
+            prop_ms += pm
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -129,16 +136,21 @@ def main():
     }
     if rank == 0:
         if prof_n:
-            us = 1e3 * prof_ms / prof_n
-            achieved = ALG_BYTES_PER_PARTICLE_STEP * N / (us * 1e-6) / 1e9
+            # dominant kernel: k_propagate (every particle through all T-1 steps in one launch per sweep).  Its
+            # "launch" covers T-1 particle-steps per particle, so the algorithmic bytes of one launch are 52 N (T-1).
+            us = 1e3 * prop_ms / args.steps
+            achieved = ALG_BYTES_PER_PARTICLE_STEP * N * (T - 1) / (us * 1e-6) / 1e9
+            resample_us = 1e3 * prof_ms / prof_n
             traffic = None
             tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
             if os.path.exists(tf):
-                traffic = json.load(open(tf)).get("k_fused_hbm_bytes_per_launch")
+                traffic = json.load(open(tf)).get("k_propagate_hbm_bytes_per_launch")
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "k_fused<2,2,8,4>", "avg_launch_us": us, "launches": prof_n,
-                "alg_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * N,
+                "traffic": traffic, "kernel": "k_propagate<2,2,8,2,2>", "avg_launch_us": us, "launches": args.steps,
+                "alg_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * N * (T - 1),
+                "second_kernel": {"kernel": "k_resample", "avg_launch_us": resample_us, "launches": prof_n,
+                                  "achieved_GBs": ALG_BYTES_PER_PARTICLE_STEP * N / (resample_us * 1e-6) / 1e9},
             }
         if args.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(pb, A.cpu().numpy(), S.cpu().numpy(), N, seed, args.cpu_steps)

@@ -117,12 +117,19 @@ int pgas_get_traces(pgas_ctx* ctx, double** x_trace, int32_t** anc_trace, double
 /* Index drawn by the last sweep at src/PGAS.py:225 (synchronises the stream). */
 int pgas_last_final_index(pgas_ctx* ctx, int64_t* idx, void* stream);
 
-/* Measurement aid (bench.py): when on, pgas_sweep brackets every launch of its dominant kernel
- * (k_fused: resampling search of step t-1 + per-particle work of step t) with HIP events on the
- * caller's stream; pgas_get_profile synchronises and returns their count and summed duration
- * for the last sweep.  No reference counterpart (the reference has no timing code). */
+/* Measurement aid (bench.py): when on, pgas_sweep brackets its kernels with HIP events on the caller's
+ * stream: every k_resample launch (per-step resampling search + softmax scans) and the k_propagate
+ * launches as a whole (every particle through all time steps).  pgas_get_profile synchronises and returns the
+ * k_resample launch count, their summed duration and the k_propagate duration of the last sweep.
+ * No reference counterpart (the reference has no timing code). */
 int pgas_set_profiling(pgas_ctx* ctx, int32_t on);
-int pgas_get_profile(pgas_ctx* ctx, int64_t* launches, double* total_ms, void* stream);
+int pgas_get_profile(pgas_ctx* ctx, int64_t* launches, double* total_ms, double* propagate_ms, void* stream);
+
+/* Tuning / test knobs.  PGAS_OPT_PROPAGATE_CHUNK: time steps per k_propagate launch (0 = the whole sweep in one launch). */
+#define PGAS_OPT_PROPAGATE_CHUNK 1
+#define PGAS_OPT_OVERLAP 3 /* 1 (default): weight recursion on an internal high-priority stream, concurrent with k_propagate */
+#define PGAS_OPT_FORCE_SLOW_RESAMPLE 2 /* 1: always use the k_resample + k_upper pair (the path taken when N > 2^20 per device) */
+int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
 
 /* Sufficient statistics of PGAS.sample_params (src/PGAS.py:294-303, BI:53-61) without the prior:
  * traj_dev (T,nx) -> T0 (M,nx), T1 (M,M) [fp64 MFMA SYRK], T2 (nx,nx); T3 = T-1.

@@ -132,18 +132,35 @@ EXPORT void oc_pack_coeff(const oc_model* m, const double* A, double* G) {
 }
 EXPORT int64_t oc_grid_size(const oc_model* m) { return grid_size(m); }
 
-/* sin(pi * j * r_d) for the J[d] frequencies of dimension d  (src/BasisFunctions.py:77-80) */
+/* sin(pi * j * r_d) for the J[d] frequencies j = j0 + q step of dimension d  (src/BasisFunctions.py:77-80).
+ * Canonical recurrences: one-dimensional bases rotate (sin, cos) by the step angle;
+ * multi-dimensional bases use the Chebyshev three-term recurrence s_{q+1} = 2 cos(step) s_q - s_{q-1}. */
 static void dim_sines(const oc_model* m, int d, const double* v, double* s) {
     double r = PGAS_FMA(v[m->sel[d]], m->alpha[d], m->beta[d]);
     double sc, cc, sd, cd;
     pgas_sincospi((double)m->j0[d] * r, &sc, &cc);
-    pgas_sincospi((double)m->jstep[d] * r, &sd, &cd);
-    s[0] = sc;
-    for (int q = 1; q < m->J[d]; ++q) {
-        double sn = PGAS_FMA(sc, cd, cc * sd);
-        double cn = PGAS_FMA(cc, cd, -(sc * sd));
-        sc = sn; cc = cn;
-        s[q] = sc;
+    if (m->jstep[d] == m->j0[d]) {
+        sd = sc;
+        cd = cc;
+    } else {
+        pgas_sincospi((double)m->jstep[d] * r, &sd, &cd);
+    }
+    if (m->D == 1) {
+        for (int q = 0; q < m->J[d]; ++q) {
+            s[q] = sc;
+            double sn = PGAS_FMA(sc, cd, cc * sd);
+            double cn = PGAS_FMA(cc, cd, -(sc * sd));
+            sc = sn; cc = cn;
+        }
+    } else {
+        double prev = (m->jstep[d] == m->j0[d]) ? 0.0 : PGAS_FMA(sc, cd, -(cc * sd)); /* sin(pi (j0 - step) r) */
+        double cur = sc, tw = cd + cd;
+        for (int q = 0; q < m->J[d]; ++q) {
+            s[q] = cur;
+            double nx = PGAS_FMA(tw, cur, -prev);
+            prev = cur;
+            cur = nx;
+        }
     }
 }
 
@@ -230,16 +247,22 @@ static void segment_scan(const double* lw, int n, double* mo, uint64_t* c, uint6
     *so = run;
 }
 
-/* Kogge-Stone inclusive scan of one group of 64 (zero padded) */
+/* Canonical inclusive scan of one group of 64 (zero padded), the "R16 tree" of DESIGN.md 4.4:
+ * Kogge-Stone inside each row of 16 (offsets 1,2,4,8), then rows 1 and 3 add the total of the row before them,
+ * then rows 2 and 3 add the value of element 31.  Elements without a partner add 0.0. */
 static void ks64(double* v) {
     double t[64];
-    for (int off = 1; off < 64; off <<= 1) {
-        for (int l = 0; l < 64; ++l) t[l] = (l >= off) ? v[l] + v[l - off] : v[l];
+    for (int off = 1; off < 16; off <<= 1) {
+        for (int l = 0; l < 64; ++l) t[l] = v[l] + ((l % 16) >= off ? v[l - off] : 0.0);
         memcpy(v, t, sizeof t);
     }
+    for (int l = 0; l < 64; ++l) t[l] = v[l] + (((l / 16) & 1) ? v[(l / 16) * 16 - 1] : 0.0);
+    memcpy(v, t, sizeof t);
+    for (int l = 0; l < 64; ++l) t[l] = v[l] + ((l / 32) ? v[31] : 0.0);
+    memcpy(v, t, sizeof t);
 }
 
-/* "KS64 tree" exclusive prefix over n values (three levels, n <= 64^3) */
+/* exclusive prefix over n values: three levels of groups of 64, each scanned by ks64 (n <= 64^3) */
 static void ks64_tree_exclusive(const double* x, int n, double* excl) {
     int n1 = (n + 63) / 64, n2 = (n1 + 63) / 64;
     double* incA = (double*)calloc((size_t)n1 * 64, sizeof(double));

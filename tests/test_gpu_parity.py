@@ -75,9 +75,16 @@ def test_basis_init_step_bit_exact(name, N):
         lw, x = lwo, xo
 
 
-@pytest.mark.parametrize("name,N", [("smo", 200), ("smo", 4096), ("smo", 5000), ("toy", 1500), ("emps", 2048), ("smo", 1 << 17)])
-def test_sweep_bit_exact(name, N):
+@pytest.mark.parametrize("name,N,opts", [
+    ("smo", 200, {}), ("smo", 4096, {}), ("smo", 5000, {}), ("toy", 1500, {}), ("emps", 2048, {}), ("smo", 1 << 17, {}),
+    ("smo", 5000, {2: 1}),            # PGAS_OPT_FORCE_SLOW_RESAMPLE: the k_resample + k_upper pair used when N > 2^20 per device
+    ("smo", 70000, {2: 1, 1: 7}),     # ... with k_propagate launched in chunks of 7 time steps
+    ("toy", 1500, {1: 1}),            # PGAS_OPT_PROPAGATE_CHUNK = 1: one k_propagate launch per step
+])
+def test_sweep_bit_exact(name, N, opts):
     pb, A, S, cm, csmc = _setup(name, N)
+    for k, v in opts.items():
+        csmc.engine.set_option(k, v)
     LS, LSinv, cS = cm.chol_parts(S)
     traj = csmc(SEED, pb.X_true, A, S)
     trajo, Xo, ANCo, lwo = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
