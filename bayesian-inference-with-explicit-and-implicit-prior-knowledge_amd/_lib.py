@@ -78,7 +78,7 @@ def load():
     L.pgas_set_profiling.restype = C.c_int
     L.pgas_set_profiling.argtypes = [vp, i32]
     L.pgas_get_profile.restype = C.c_int
-    L.pgas_get_profile.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(C.c_double), vp]
+    L.pgas_get_profile.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), vp]
     L.pgas_set_option.restype = C.c_int
     L.pgas_set_option.argtypes = [vp, i32, i64]
     _lib = L
@@ -236,10 +236,10 @@ class Engine:
         self._chk(self.lib.pgas_set_profiling(self._h, 1 if on else 0), "pgas_set_profiling")
 
     def profile(self):
-        """(k_resample launches, their total ms, k_propagate total ms) of the last sweep (synchronises)."""
-        n, ms, pm = C.c_int64(), C.c_double(), C.c_double()
-        self._chk(self.lib.pgas_get_profile(self._h, C.byref(n), C.byref(ms), C.byref(pm), self._stream()), "pgas_get_profile")
-        return int(n.value), float(ms.value), float(pm.value)
+        """(k_resample launches, their total ms, k_propagate launches, their total ms) of the last sweep (synchronises)."""
+        n, ms, pn, pm = C.c_int64(), C.c_double(), C.c_int64(), C.c_double()
+        self._chk(self.lib.pgas_get_profile(self._h, C.byref(n), C.byref(ms), C.byref(pn), C.byref(pm), self._stream()), "pgas_get_profile")
+        return int(n.value), float(ms.value), int(pn.value), float(pm.value)
 
     def set_option(self, option, value):
         self._chk(self.lib.pgas_set_option(self._h, int(option), int(value)), "pgas_set_option")

@@ -97,8 +97,8 @@ struct pgas_ctx {
     // optional per-launch timing of the dominant kernel (pgas_set_profiling)
     int profiling = 0;
     std::vector<hipEvent_t> ev;      // pairs (start, stop) around each k_resample launch of the last sweep
-    hipEvent_t ev_prop[2] = {nullptr, nullptr};  // around the k_propagate launches
-    int prop_steps = 0;
+    std::vector<hipEvent_t> evp;     // pairs (start, stop) around each k_propagate launch of the last sweep
+    int evp_used = 0;
     int ev_used = 0;
     std::string err;
 };
@@ -257,7 +257,7 @@ void pgas_destroy(pgas_ctx* c) {
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
     hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
-    for (hipEvent_t e : c->ev_prop) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : c->evp) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
     if (c->ev_start) hipEventDestroy(c->ev_start);
     if (c->ev_done) hipEventDestroy(c->ev_done);
@@ -381,7 +381,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, c->x_trace);
     KCHK(c, "k_init");
     c->ev_used = 0;
-    c->prop_steps = 0;
+    c->evp_used = 0;
     if (T == 1) {
         HIPCHK(c, hipMemsetAsync(c->logw_last, 0, N * sizeof(double), st));
     } else {
@@ -392,8 +392,6 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
                 c->ev.resize(2 * (size_t)T);
                 for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
             }
-            for (hipEvent_t& e : c->ev_prop) if (!e) HIPCHK(c, hipEventCreate(&e));
-            HIPCHK(c, hipEventRecord(c->ev_prop[0], st));
         }
         // pipeline A (caller's stream): every particle through all time steps; independent of the weights (quirk Q1).
         // pipeline B (internal high-priority stream when overlap is on): the weight recursion, gated chunk by chunk on
@@ -422,13 +420,21 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
         // launches are issued chunk by chunk, pipeline A first, so both device queues stay fed
         for (int ci = 0; ci < nchunk; ++ci) {
             const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+            if (c->profiling) {
+                while ((int)c->evp.size() < c->evp_used + 2) {
+                    hipEvent_t e;
+                    HIPCHK(c, hipEventCreate(&e));
+                    c->evp.push_back(e);
+                }
+                HIPCHK(c, hipEventRecord(c->evp[c->evp_used], st));
+            }
             hipLaunchKernelGGL(c->var.prop, grid, blk, 0, st, md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
             KCHK(c, "k_propagate");
+            if (c->profiling) { HIPCHK(c, hipEventRecord(c->evp[c->evp_used + 1], st)); c->evp_used += 2; }
             if (c->overlap) {
                 HIPCHK(c, hipEventRecord(c->ev_chunk[ci], st));
                 HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_chunk[ci], 0));
             }
-            if (ci == nchunk - 1 && c->profiling) HIPCHK(c, hipEventRecord(c->ev_prop[1], st));
             // launch t resamples step t-1 (t > 1) and scans step t (t < T); the last chunk also runs launch T
             const int tend = ci == nchunk - 1 ? T + 1 : t1;
             for (int t = t0; t < tend; ++t) {
@@ -458,7 +464,6 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
                 }
             }
         }
-        c->prop_steps = T - 1;
         if (c->overlap) {
             HIPCHK(c, hipEventRecord(c->ev_done, c->sB));
             HIPCHK(c, hipStreamWaitEvent(st, c->ev_done, 0));
@@ -523,9 +528,9 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
     FAIL(c, PGAS_E_ARG, "pgas_set_option: unknown option %d", option);
 }
 
-int pgas_get_profile(pgas_ctx* c, int64_t* launches, double* total_ms, double* propagate_ms, void* stream) {
+int pgas_get_profile(pgas_ctx* c, int64_t* launches, double* total_ms, int64_t* propagate_launches, double* propagate_ms, void* stream) {
     if (!c) return PGAS_E_ARG;
-    if (!launches || !total_ms || !propagate_ms) FAIL(c, PGAS_E_ARG, "pgas_get_profile: NULL argument");
+    if (!launches || !total_ms || !propagate_launches || !propagate_ms) FAIL(c, PGAS_E_ARG, "pgas_get_profile: NULL argument");
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
     double sum = 0.0;
@@ -536,12 +541,14 @@ int pgas_get_profile(pgas_ctx* c, int64_t* launches, double* total_ms, double* p
     }
     *launches = c->ev_used / 2;
     *total_ms = sum;
-    *propagate_ms = 0.0;
-    if (c->prop_steps > 0 && c->ev_prop[0]) {
+    double psum = 0.0;
+    for (int i = 0; i + 1 < c->evp_used; i += 2) {
         float ms = 0.f;
-        HIPCHK(c, hipEventElapsedTime(&ms, c->ev_prop[0], c->ev_prop[1]));
-        *propagate_ms = ms;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->evp[i], c->evp[i + 1]));
+        psum += ms;
     }
+    *propagate_launches = c->evp_used / 2;
+    *propagate_ms = psum;
     return PGAS_OK;
 }
 

@@ -105,13 +105,14 @@ def main():
         pg.cSMC(seed + 1000 + w, ref, A, S)
     barrier()
     t0 = time.perf_counter()
-    prof_n, prof_ms, prop_ms = 0, 0.0, 0.0
+    prof_n, prof_ms, prop_n, prop_ms = 0, 0.0, 0, 0.0
     for k in range(args.steps):
         pg.cSMC(seed + k, ref, A, S)
         if not args.no_profile:
-            n, ms, pm = eng.profile()   # synchronises this sweep; the events sit inside the timed region
+            n, ms, pn, pm = eng.profile()   # synchronises this sweep; the events sit inside the timed region
             prof_n += n
             prof_ms += ms
+            prop_n += pn
             prop_ms += pm
     barrier()
     dt = time.perf_counter() - t0
@@ -136,21 +137,27 @@ def main():
     }
     if rank == 0:
         if prof_n:
-            # dominant kernel: k_propagate (every particle through all T-1 steps in one launch per sweep).  Its
-            # "launch" covers T-1 particle-steps per particle, so the algorithmic bytes of one launch are 52 N (T-1).
-            us = 1e3 * prop_ms / args.steps
-            achieved = ALG_BYTES_PER_PARTICLE_STEP * N * (T - 1) / (us * 1e-6) / 1e9
-            resample_us = 1e3 * prof_ms / prof_n
-            traffic = None
+            # Dominant kernel (largest total duration in profiles/r01_kernel_stats.csv): k_resample_fast, one launch per time step,
+            # N particle-steps per launch -> algorithmic bytes per launch = 52 N.  k_propagate (the other half of every
+            # particle-step: basis, transition, noise) is reported next to it; it covers `chunk` time steps per launch.
+            us = 1e3 * prof_ms / prof_n
+            achieved = ALG_BYTES_PER_PARTICLE_STEP * N / (us * 1e-6) / 1e9
+            p_us = 1e3 * prop_ms / max(prop_n, 1)
+            p_steps = (T - 1) * args.steps / max(prop_n, 1)
+            traffic, p_traffic = None, None
             tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
             if os.path.exists(tf):
-                traffic = json.load(open(tf)).get("k_propagate_hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic, p_traffic = tj.get("k_resample_fast_hbm_bytes_per_launch"), tj.get("k_propagate_hbm_bytes_per_step")
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "k_propagate<2,2,8,2,2>", "avg_launch_us": us, "launches": args.steps,
-                "alg_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * N * (T - 1),
-                "second_kernel": {"kernel": "k_resample", "avg_launch_us": resample_us, "launches": prof_n,
-                                  "achieved_GBs": ALG_BYTES_PER_PARTICLE_STEP * N / (resample_us * 1e-6) / 1e9},
+                "traffic": traffic, "kernel": "k_resample_fast", "avg_launch_us": us, "launches": prof_n,
+                "alg_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * N,
+                "second_kernel": {"kernel": "k_propagate<2,2,8,2,2>", "avg_launch_us": p_us, "launches": prop_n, "steps_per_launch": p_steps,
+                                  "achieved_GBs": ALG_BYTES_PER_PARTICLE_STEP * N * p_steps / (p_us * 1e-6) / 1e9,
+                                  "traffic_per_step": p_traffic},
+                "note": "the two kernels run concurrently on two streams; both are fp64-VALU-bound (DESIGN.md section 5), "
+                        "so the HBM fraction understates how close they are to their own limit",
             }
         if args.cpu_steps > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(pb, A.cpu().numpy(), S.cpu().numpy(), N, seed, args.cpu_steps)

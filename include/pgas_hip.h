@@ -118,12 +118,13 @@ int pgas_get_traces(pgas_ctx* ctx, double** x_trace, int32_t** anc_trace, double
 int pgas_last_final_index(pgas_ctx* ctx, int64_t* idx, void* stream);
 
 /* Measurement aid (bench.py): when on, pgas_sweep brackets its kernels with HIP events on the caller's
- * stream: every k_resample launch (per-step resampling search + softmax scans) and the k_propagate
- * launches as a whole (every particle through all time steps).  pgas_get_profile synchronises and returns the
- * k_resample launch count, their summed duration and the k_propagate duration of the last sweep.
+ * stream(s): every per-step k_resample(_fast) launch (resampling search + softmax scans) and every k_propagate
+ * launch (all particles through a chunk of time steps).  pgas_get_profile synchronises and returns, for the last
+ * sweep, the launch counts and summed launch durations of the two kernels.
  * No reference counterpart (the reference has no timing code). */
 int pgas_set_profiling(pgas_ctx* ctx, int32_t on);
-int pgas_get_profile(pgas_ctx* ctx, int64_t* launches, double* total_ms, double* propagate_ms, void* stream);
+int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample_ms, int64_t* propagate_launches,
+                     double* propagate_ms, void* stream);
 
 /* Tuning / test knobs.  PGAS_OPT_PROPAGATE_CHUNK: time steps per k_propagate launch (0 = the whole sweep in one launch). */
 #define PGAS_OPT_PROPAGATE_CHUNK 1
