@@ -36,6 +36,7 @@ EXPORTS = [
     "pgas_create", "pgas_destroy", "pgas_last_error", "pgas_segment_size", "pgas_set_params", "pgas_basis_eval",
     "pgas_aux_states", "pgas_init_state", "pgas_step", "pgas_sweep", "pgas_get_traces", "pgas_last_final_index",
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
+    "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
 ]
 
 _lib = None
@@ -81,6 +82,18 @@ def load():
     L.pgas_get_profile.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), vp]
     L.pgas_set_option.restype = C.c_int
     L.pgas_set_option.argtypes = [vp, i32, i64]
+    L.pgas_shard_setup.restype = C.c_int
+    L.pgas_shard_setup.argtypes = [vp, i32, i32]
+    L.pgas_shard_buffers.restype = C.c_int
+    L.pgas_shard_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
+    L.pgas_shard_set_peer.restype = C.c_int
+    L.pgas_shard_set_peer.argtypes = [vp, i32, C.POINTER(vp)]
+    L.pgas_shard_run.restype = C.c_int
+    L.pgas_shard_run.argtypes = [vp, i32, i32, i32, u64, vp, vp, vp]
+    L.pgas_ipc_export.restype = C.c_int
+    L.pgas_ipc_export.argtypes = [vp, i32, C.c_char_p]
+    L.pgas_ipc_open.restype = C.c_int
+    L.pgas_ipc_open.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     _lib = L
     return L
 
@@ -243,6 +256,44 @@ class Engine:
 
     def set_option(self, option, value):
         self._chk(self.lib.pgas_set_option(self._h, int(option), int(value)), "pgas_set_option")
+
+    # -------------------------------------------------------------- particle sharding (pgas_amd/sharded.py)
+    def shard_setup(self, rank, world):
+        self._chk(self.lib.pgas_shard_setup(self._h, rank, world), "pgas_shard_setup")
+        self.rank, self.world = rank, world
+
+    def shard_buffers(self):
+        """(list of 15 device pointers, (nsegp, N_local, T)) -- see include/pgas_hip.h."""
+        out = (C.c_void_p * 15)()
+        sz = (C.c_int64 * 3)()
+        self._chk(self.lib.pgas_shard_buffers(self._h, out, sz), "pgas_shard_buffers")
+        return [int(p or 0) for p in out], tuple(int(v) for v in sz)
+
+    def shard_set_peer(self, peer, ptrs7):
+        arr = (C.c_void_p * 7)(*[C.c_void_p(p) for p in ptrs7])
+        self._chk(self.lib.pgas_shard_set_peer(self._h, peer, arr), "pgas_shard_set_peer")
+
+    def shard_run(self, phase, t=0, t_aux=0, seed=0, ref=None, traj=None):
+        self._chk(
+            self.lib.pgas_shard_run(self._h, phase, t, t_aux, seed, None if ref is None else ref.data_ptr(),
+                                    None if traj is None else traj.data_ptr(), self._stream()),
+            "pgas_shard_run",
+        )
+
+    def ipc_export(self, which):
+        buf = C.create_string_buffer(64)
+        self._chk(self.lib.pgas_ipc_export(self._h, which, buf), "pgas_ipc_export")
+        return bytes(buf.raw)
+
+    def ipc_open(self, handle):
+        p = C.c_void_p()
+        self._chk(self.lib.pgas_ipc_open(self._h, handle, C.byref(p)), "pgas_ipc_open")
+        return int(p.value)
+
+    def dev_tensor(self, ptr, shape, dtype):
+        """torch view of library-owned device memory."""
+        typestr = {torch.float64: "<f8", torch.int64: "<i8", torch.int32: "<i4"}[dtype]
+        return torch.as_tensor(_DevView(ptr, shape, typestr, self), device=self.device)
 
     def suffstats(self, traj):
         traj = self._dev(traj, shape=(self.T, self.nx))

@@ -86,6 +86,13 @@ struct pgas_ctx {
     double* ln_buf = nullptr;   // (T, nseg*SEG) log p(y_t | x_t)
     double* laux_own[2] = {nullptr, nullptr};  // laux of the two step-API scan buffers
     int prop_chunk = 0;         // time steps per k_propagate launch (0 = whole sweep)
+    Peers peers{};              // world == 1 unless pgas_shard_setup was called
+    const uint64_t* peer_c1[2][PG_MAX_RANKS] = {};  // per scan-buffer parity
+    const uint64_t* peer_c2[2][PG_MAX_RANKS] = {};
+    bool sharded = false;
+    int rank = 0, world = 1;
+    double* segm_g[2] = {nullptr, nullptr};   // gathered partials (sharded mode): (world, 2, nsegp) per scan buffer
+    uint64_t* segs_g[2] = {nullptr, nullptr};
     unsigned launch_tag = 0;    // unique id per k_resample_fast launch (hand-off word tag)
     int force_slow = 0;         // 1: never use k_resample_fast (test hook for the k_resample + k_upper path)
     int overlap = 1;            // 1: run the weight recursion on an internal stream concurrently with k_propagate
@@ -138,10 +145,15 @@ static int alloc_scanbufs(pgas_ctx* c, ScanBufs* sb) {
     HIPCHK(c, hipMalloc(&sb->cm, 2 * nsegp * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->hdr, sizeof(UpperHdr)));
     HIPCHK(c, hipMemset(sb->hdr, 0, sizeof(UpperHdr)));
+    sb->segm_w = sb->segm;
+    sb->segs_w = sb->segs;
+    sb->nseg_l = 0x40000000;
+    sb->rank_stride = 0;
+    sb->nsegp_g = nsegp;
     return PGAS_OK;
 }
 static void free_scanbufs(ScanBufs* sb) {
-    hipFree(sb->laux); hipFree(sb->c1); hipFree(sb->c2); hipFree(sb->segm); hipFree(sb->segs);
+    hipFree(sb->laux); hipFree(sb->c1); hipFree(sb->c2); hipFree(sb->segm_w); hipFree(sb->segs_w);  // segm/segs alias these or the gathered arrays
     hipFree(sb->excl); hipFree(sb->scale); hipFree(sb->cm); hipFree(sb->hdr);
     *sb = ScanBufs{};
 }
@@ -167,6 +179,8 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
     DevModel& md = c->md;
     md.N = d->N; md.T = d->T; md.nx = d->nx; md.ny = d->ny; md.nu = d->nu; md.D = d->D; md.M = d->M;
     md.nseg = (int)nseg64;
+    md.p0 = 0; md.Ng = d->N; md.nseg_g = md.nseg;
+    c->peers.world = 1; c->peers.nseg_l = md.nseg; c->peers.Nl = d->N;
     md.nrm = d->nrm; md.cR = d->cR;
     for (int k = 0; k < d->D; ++k) {
         if (d->sel[k] < 0 || d->sel[k] >= d->nx + d->nu) FAIL(c, PGAS_E_ARG, "pgas_create: sel[%d] = %d out of range", k, d->sel[k]);
@@ -255,6 +269,7 @@ void pgas_destroy(pgas_ctx* c) {
     hipSetDevice(c->device);
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
+    hipFree(c->segm_g[0]); hipFree(c->segm_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
     hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (hipEvent_t e : c->evp) hipEventDestroy(e);
@@ -263,6 +278,7 @@ void pgas_destroy(pgas_ctx* c) {
     if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->sB) hipStreamDestroy(c->sB);
     free_scanbufs(&c->sb[0]); free_scanbufs(&c->sb[1]);
+    (void)hipGetLastError();  // do not leave a sticky error behind for the next context
     delete c;
 }
 
@@ -320,9 +336,9 @@ int pgas_init_state(pgas_ctx* c, uint64_t seed, const double* ref0_host, double*
 }
 
 static int launch_upper(pgas_ctx* c, const ScanBufs& sb, int nblocks, int search_block, double u, int final_mode, hipStream_t st) {
-    const int groups = (c->md.nseg + 63) / 64;
+    const int groups = (c->md.nseg_g + 63) / 64;
     auto kern = groups <= 4 * PG_UPPER_WAVES ? k_upper<4> : groups <= 8 * PG_UPPER_WAVES ? k_upper<8> : k_upper<PG_MAX_GROUPS / PG_UPPER_WAVES>;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(PG_UPPER_THREADS), 0, st, c->md.N, c->md.nseg, sb, search_block, u, final_mode);
+    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(PG_UPPER_THREADS), 0, st, c->md.Ng, c->md.nseg_g, sb, c->peers, search_block, u, final_mode);
     KCHK(c, "k_upper");
     return PGAS_OK;
 }
@@ -369,6 +385,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     if (!c) return PGAS_E_ARG;
     if (!ref_dev || !traj_dev) FAIL(c, PGAS_E_ARG, "pgas_sweep: NULL argument");
     if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_sweep: call pgas_set_params first");
+    if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_sweep: this context is a shard; drive it with pgas_shard_run");
     HIPCHK(c, hipSetDevice(c->device));
     int rc = ensure_traces(c);
     if (rc) return rc;
@@ -454,7 +471,8 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
                     hipLaunchKernelGGL(k_resample_fast, dim3(md.nseg + 1), blk, 0, sb_stream, md, t, mode, ++c->launch_tag, u1p, u2p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
                     KCHK(c, "k_resample_fast");
                 } else {
-                    hipLaunchKernelGGL(k_resample, grid, blk, 0, sb_stream, md, t, mode, u1p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
+                    hipLaunchKernelGGL(k_resample, grid, blk, 0, sb_stream, md, t, mode, u1p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, c->peers,
+                                       (int64_t)((size_t)(t - 1) * np), anc, lwo);
                     KCHK(c, "k_resample");
                 }
                 if (timed) { HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], sb_stream)); c->ev_used += 2; }
@@ -477,7 +495,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     KCHK(c, "k_segscan");
     rc = launch_upper(c, sf, 1, 0, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), 1, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, st, N, T, nx, c->x_trace, c->anc_trace, sf.hdr, traj_dev);
+    hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, st, N, T, nx, c->x_trace, c->anc_trace, c->peers, sf.hdr, traj_dev);
     KCHK(c, "k_backtrace");
     return PGAS_OK;
 }
@@ -557,6 +575,167 @@ int pgas_debug_stamps(unsigned long long* out /* 2048*16 */) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 2048 * 16) == hipSuccess ? 0 : -2;
 }
 #endif
+
+
+// ------------------------------------------------------------------------------------------------
+// Particle-sharded sweep (one context per rank, each owning N_local = N_global / world particles).
+// The host (pgas_amd/sharded.py) drives the phases and performs the one collective per step -- an
+// all-gather of the per-segment softmax partials -- with torch.distributed (RCCL); peers' scan buffers
+// are read directly through xGMI peer mappings whose pointers are installed with pgas_shard_set_peer.
+// ------------------------------------------------------------------------------------------------
+int pgas_shard_setup(pgas_ctx* c, int32_t rank, int32_t world) {
+    if (!c) return PGAS_E_ARG;
+    if (world < 1 || world > PG_MAX_RANKS || rank < 0 || rank >= world) FAIL(c, PGAS_E_ARG, "pgas_shard_setup: bad rank/world %d/%d", rank, world);
+    if (c->md.N % PGAS_SEG) FAIL(c, PGAS_E_ARG, "pgas_shard_setup: local particle count %d must be a multiple of %d", c->md.N, PGAS_SEG);
+    if ((int64_t)c->md.nseg * world > PG_MAX_NSEG) FAIL(c, PGAS_E_ARG, "pgas_shard_setup: %d global segments exceed %d", c->md.nseg * world, PG_MAX_NSEG);
+    if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_setup: already set up");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc = ensure_traces(c);
+    if (rc) return rc;
+    DevModel& md = c->md;
+    c->rank = rank; c->world = world;
+    md.p0 = (int64_t)rank * md.N;
+    md.Ng = md.N * world;
+    md.nseg_g = md.nseg * world;
+    c->peers.world = world; c->peers.nseg_l = md.nseg; c->peers.Nl = md.N;
+    const int nsegp = c->sb[0].nsegp, nsegp_g = (md.nseg_g + 63) / 64 * 64;
+    for (int i = 0; i < 2; ++i) {
+        ScanBufs& sb = c->sb[i];
+        HIPCHK(c, hipMalloc(&c->segm_g[i], (size_t)world * 2 * nsegp * sizeof(double)));
+        HIPCHK(c, hipMalloc(&c->segs_g[i], (size_t)world * 2 * nsegp * sizeof(uint64_t)));
+        HIPCHK(c, hipMemset(c->segm_g[i], 0, (size_t)world * 2 * nsegp * sizeof(double)));
+        HIPCHK(c, hipMemset(c->segs_g[i], 0, (size_t)world * 2 * nsegp * sizeof(uint64_t)));
+        sb.segm_w = sb.segm; sb.segs_w = sb.segs;          // local scans keep writing their own (2, nsegp) block
+        sb.segm = c->segm_g[i]; sb.segs = c->segs_g[i];    // the cross-segment scan reads the gathered (world, 2, nsegp)
+        sb.nseg_l = md.nseg; sb.rank_stride = 2 * nsegp; sb.nsegp_g = nsegp_g;
+        hipFree(sb.excl); hipFree(sb.scale); hipFree(sb.cm);
+        HIPCHK(c, hipMalloc(&sb.excl, 2 * (size_t)nsegp_g * sizeof(double)));
+        HIPCHK(c, hipMalloc(&sb.scale, 2 * (size_t)nsegp_g * sizeof(double)));
+        HIPCHK(c, hipMalloc(&sb.cm, 2 * (size_t)nsegp_g * sizeof(double)));
+        c->peer_c1[i][rank] = sb.c1; c->peer_c2[i][rank] = sb.c2;
+    }
+    c->peers.laux[rank] = c->la_buf; c->peers.x[rank] = c->x_trace; c->peers.anc[rank] = c->anc_trace;
+    c->sharded = true;
+    return PGAS_OK;
+}
+
+/* out[15]: c1[0], c1[1], c2[0], c2[1], la_buf, x_trace, anc_trace, segm_w[0], segm_w[1], segs_w[0], segs_w[1],
+ *          segm_g[0], segm_g[1], segs_g[0], segs_g[1]; sizes[3]: nsegp (local padded segments), N_local, T */
+int pgas_shard_buffers(pgas_ctx* c, void** out, int64_t* sizes) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_buffers: call pgas_shard_setup first");
+    if (!out || !sizes) FAIL(c, PGAS_E_ARG, "pgas_shard_buffers: NULL argument");
+    out[0] = c->sb[0].c1; out[1] = c->sb[1].c1; out[2] = c->sb[0].c2; out[3] = c->sb[1].c2;
+    out[4] = c->la_buf; out[5] = c->x_trace; out[6] = c->anc_trace;
+    out[7] = c->sb[0].segm_w; out[8] = c->sb[1].segm_w; out[9] = c->sb[0].segs_w; out[10] = c->sb[1].segs_w;
+    out[11] = c->segm_g[0]; out[12] = c->segm_g[1]; out[13] = c->segs_g[0]; out[14] = c->segs_g[1];
+    sizes[0] = c->sb[0].nsegp; sizes[1] = c->md.N; sizes[2] = c->md.T;
+    return PGAS_OK;
+}
+
+/* bufs[7]: the peer's c1[0], c1[1], c2[0], c2[1], la_buf, x_trace, anc_trace as mapped into THIS process */
+int pgas_shard_set_peer(pgas_ctx* c, int32_t peer, const void* const* bufs) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_set_peer: call pgas_shard_setup first");
+    if (peer < 0 || peer >= c->world || !bufs) FAIL(c, PGAS_E_ARG, "pgas_shard_set_peer: bad argument");
+    c->peer_c1[0][peer] = (const uint64_t*)bufs[0]; c->peer_c1[1][peer] = (const uint64_t*)bufs[1];
+    c->peer_c2[0][peer] = (const uint64_t*)bufs[2]; c->peer_c2[1][peer] = (const uint64_t*)bufs[3];
+    c->peers.laux[peer] = (const double*)bufs[4]; c->peers.x[peer] = (const double*)bufs[5]; c->peers.anc[peer] = (const int32_t*)bufs[6];
+    return PGAS_OK;
+}
+
+int pgas_shard_run(pgas_ctx* c, int32_t phase, int32_t t, int32_t t_aux, uint64_t seed, const double* ref_dev, double* traj_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_run: call pgas_shard_setup first");
+    if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_shard_run: call pgas_set_params first");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const DevModel& md = c->md;
+    const int N = md.N, T = md.T;
+    const dim3 grid(md.nseg), blk(PG_BLK);
+    const size_t np = (size_t)md.nseg * PGAS_SEG;
+    for (int r = 0; r < c->world; ++r)
+        if (!c->peers.laux[r] || !c->peer_c1[0][r]) FAIL(c, PGAS_E_STATE, "pgas_shard_run: buffers of rank %d not installed", r);
+    auto peers_for = [&](int parity) {
+        Peers p = c->peers;
+        for (int r = 0; r < c->world; ++r) { p.c1[r] = c->peer_c1[parity][r]; p.c2[r] = c->peer_c2[parity][r]; }
+        return p;
+    };
+    switch (phase) {
+    case PGAS_SHARD_INIT:
+        if (!ref_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_run(INIT): ref_dev == NULL");
+        hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, c->x_trace);
+        KCHK(c, "k_init");
+        return PGAS_OK;
+    case PGAS_SHARD_PROPAGATE:  // time steps [t, t_aux)
+        if (!ref_dev || t < 1 || t_aux > T || t >= t_aux) FAIL(c, PGAS_E_ARG, "pgas_shard_run(PROPAGATE): bad range [%d,%d)", t, t_aux);
+        hipLaunchKernelGGL(c->var.prop, grid, blk, 0, st, md, c->tp, seed, t, t_aux, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
+        KCHK(c, "k_propagate");
+        return PGAS_OK;
+    case PGAS_SHARD_RESAMPLE: {  // launch t in [1, T]: resample step t-1 (t > 1), scan step t (t < T)
+        if (t < 1 || t > T) FAIL(c, PGAS_E_ARG, "pgas_shard_run(RESAMPLE): t = %d outside [1, %d]", t, T);
+        ScanBufs sp = c->sb[(t - 1) & 1], sn = c->sb[t & 1];
+        sp.laux = c->la_buf + (size_t)(t - 1) * np;
+        sn.laux = c->la_buf + (size_t)(t < T ? t : T - 1) * np;
+        const int mode = (t < T ? PG_RS_SCAN : 0) | (t > 1 ? PG_RS_SEARCH : 0);
+        hipLaunchKernelGGL(k_resample, grid, blk, 0, st, md, t, mode, t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)) : 0.0,
+                           t < T ? c->la_buf + (size_t)t * np : (const double*)nullptr, t < T ? c->h_buf + (size_t)t * np : (const double*)nullptr,
+                           c->ln_buf + (size_t)(t - 1) * np, sp, sn, peers_for((t - 1) & 1), (int64_t)((size_t)(t - 1) * np),
+                           t > 1 ? c->anc_trace + (size_t)(t - 2) * N : (int32_t*)nullptr, t == T ? c->logw_last : (double*)nullptr);
+        KCHK(c, "k_resample");
+        return PGAS_OK;
+    }
+    case PGAS_SHARD_UPPER: {  // after the all-gather of step t's partials
+        if (t < 1 || t >= T) FAIL(c, PGAS_E_ARG, "pgas_shard_run(UPPER): t = %d outside [1, %d)", t, T);
+        Peers keep = c->peers;
+        c->peers = peers_for(t & 1);
+        int rc = launch_upper(c, c->sb[t & 1], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
+        c->peers = keep;
+        return rc;
+    }
+    case PGAS_SHARD_FINAL_SCAN:
+        hipLaunchKernelGGL(k_segscan, grid, blk, 0, st, N, c->logw_last, c->sb[T & 1]);
+        KCHK(c, "k_segscan");
+        return PGAS_OK;
+    case PGAS_SHARD_FINAL_UPPER: {
+        Peers keep = c->peers;
+        c->peers = peers_for(T & 1);
+        int rc = launch_upper(c, c->sb[T & 1], 1, 0, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), 1, st);
+        c->peers = keep;
+        return rc;
+    }
+    case PGAS_SHARD_BACKTRACE:
+        if (!traj_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_run(BACKTRACE): traj_dev == NULL");
+        hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, st, N, T, md.nx, c->x_trace, c->anc_trace, c->peers, c->sb[T & 1].hdr, traj_dev);
+        KCHK(c, "k_backtrace");
+        return PGAS_OK;
+    default:
+        FAIL(c, PGAS_E_ARG, "pgas_shard_run: unknown phase %d", phase);
+    }
+}
+
+/* xGMI / IPC plumbing for peers in OTHER processes: export a 64-byte handle of one of this context's buffers
+ * (index as in pgas_shard_buffers, 0..6) and map a peer's handle into this process. */
+int pgas_ipc_export(pgas_ctx* c, int32_t which, void* handle64) {
+    if (!c) return PGAS_E_ARG;
+    void* bufs[15]; int64_t sz[3];
+    int rc = pgas_shard_buffers(c, bufs, sz);
+    if (rc) return rc;
+    if (which < 0 || which > 6 || !handle64) FAIL(c, PGAS_E_ARG, "pgas_ipc_export: bad argument");
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, bufs[which]));
+    return PGAS_OK;
+}
+int pgas_ipc_open(pgas_ctx* c, const void* handle64, void** ptr) {
+    if (!c) return PGAS_E_ARG;
+    if (!handle64 || !ptr) FAIL(c, PGAS_E_ARG, "pgas_ipc_open: NULL argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle64, sizeof h);
+    HIPCHK(c, hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
+    return PGAS_OK;
+}
 
 int pgas_suffstats(pgas_ctx* c, const double* traj_dev, double* T0_dev, double* T1_dev, double* T2_dev, void* stream) {
     if (!c) return PGAS_E_ARG;

@@ -53,7 +53,11 @@ struct DevModel {
     double LRinv[PGAS_MAX_NY * PGAS_MAX_NY];
     double cR;
     int32_t JP;       // padded innermost grid extent
-    int32_t nseg;     // ceil(N / PGAS_SEG)
+    int32_t nseg;     // ceil(N / PGAS_SEG): segments of THIS device
+    // particle sharding (pgas_shard_setup; single device: p0 = 0, Ng = N, nseg_g = nseg)
+    int64_t p0;       // global index of local particle 0
+    int32_t Ng;       // global particle count
+    int32_t nseg_g;   // global segment count
     const double* y;  // device (T,ny)
     const double* u;  // device (T,nu)
 };
@@ -71,17 +75,32 @@ struct UpperHdr {      // written by k_upper
     unsigned long long ref_granule;  // k_resample_fast: {launch tag : 32, ancestor of the conditioned particle : 32}, one 8-byte store
 };
 
+#define PG_MAX_RANKS 8
+struct Peers {         // device pointers of every rank's buffers (xGMI peer mappings); world == 1: this device only
+    const uint64_t* c1[PG_MAX_RANKS];   // the c1 buffer being READ this launch
+    const uint64_t* c2[PG_MAX_RANKS];
+    const double* laux[PG_MAX_RANKS];   // la_buf bases (row offset added in the kernel)
+    const double* x[PG_MAX_RANKS];      // x_trace bases
+    const int32_t* anc[PG_MAX_RANKS];   // anc_trace bases
+    int32_t world, nseg_l, Nl;          // ranks, segments per rank, particles per rank
+};
+
 struct ScanBufs {      // per-step scan scratch (device)
     double* laux;      // (nseg*SEG)
     uint64_t* c1;      // (nseg*SEG) quantised inclusive cumsum of the resampling weights
     uint64_t* c2;      // (nseg*SEG) same for the ancestor weights
-    double* segm;      // (2, nsegp) segment maxima
-    uint64_t* segs;    // (2, nsegp) segment totals
+    double* segm;      // segment maxima as READ by the cross-segment scan: (ranks, 2, nsegp) after the all-gather
+    uint64_t* segs;    // segment totals, same layout
+    double* segm_w;    // (2, nsegp) where this device's segment scans WRITE (== segm on a single device)
+    uint64_t* segs_w;
+    int32_t nseg_l;    // segments per rank in segm/segs (single device: >= nseg, so every segment maps to "rank" 0)
+    int32_t rank_stride;  // words between two ranks' blocks in segm/segs (2 * nsegp_local)
     double* excl;      // (2, nsegp)
     double* scale;     // (2, nsegp)
     double* cm;        // (2, nsegp) running max of the segment-end CDF numerators
     UpperHdr* hdr;
-    int32_t nsegp;     // padded nseg (multiple of 64)
+    int32_t nsegp;     // padded LOCAL nseg (multiple of 64): stride between the two CDFs in segm/segs
+    int32_t nsegp_g;   // padded global nseg: stride between the two CDFs in excl/scale/cm
 };
 
 // ------------------------------------------------------------------------------------------
@@ -429,7 +448,7 @@ __global__ __launch_bounds__(PG_BLK) void k_init(DevModel md, uint64_t seed, con
     const int64_t p = (int64_t)blockIdx.x * PG_BLK + threadIdx.x;
     if (p >= md.N) return;
     double z[2];
-    pgas_rng_normals(seed, PGAS_STREAM_INIT, 0u, (uint64_t)p, NX, z);
+    pgas_rng_normals(seed, PGAS_STREAM_INIT, 0u, (uint64_t)(md.p0 + p), NX, z);
     double xv[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) {
@@ -438,7 +457,7 @@ __global__ __launch_bounds__(PG_BLK) void k_init(DevModel md, uint64_t seed, con
         for (int l = 0; l <= k; ++l) v = PGAS_FMA(m0L0[NX + k * NX + l], z[l], v);
         xv[k] = v;
     }
-    if (p == md.N - 1) {
+    if (md.p0 + p == md.Ng - 1) {
 #pragma unroll
         for (int k = 0; k < NX; ++k) xv[k] = ref0[k];
     }
@@ -565,7 +584,7 @@ __device__ __forceinline__ void propagate_particles(const DevModel& md, const Tr
 #pragma unroll
         for (int r = 0; r < PG_PPT; ++r) {
             const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-            w[r] = pgas_rng_block(seed, PGAS_STREAM_PROP, 0u, (uint32_t)t, (uint64_t)pi);
+            w[r] = pgas_rng_block(seed, PGAS_STREAM_PROP, 0u, (uint32_t)t, (uint64_t)(md.p0 + pi));
         }
         pgas_normal_pair_n(w, z0, z1, PG_PPT);
     }
@@ -588,7 +607,7 @@ __device__ __forceinline__ void propagate_particles(const DevModel& md, const Tr
             double v = aux[r][k];
 #pragma unroll
             for (int l = 0; l <= k; ++l) v = PGAS_FMA(tp.LS[k * NX + l], z[l], v);
-            xnew[r][k] = (pi == md.N - 1) ? rf[k] : v;
+            xnew[r][k] = (md.p0 + pi == md.Ng - 1) ? rf[k] : v;
         }
     }
 }
@@ -664,7 +683,7 @@ __global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, TransParams tp, i
         lwp[r] = (logw_prev != nullptr && pi < md.N) ? logw_prev[pi] : 0.0;
     }
     front_particles<NX, D, JIN, P>(md, tp, t, seed, ref_t, seg, xv, lwp, x_new, sb.laux, lw);
-    segment_scan<2>(sm, lw, seg, sb.nsegp, sb.c1, sb.c2, sb.segm, sb.segs);
+    segment_scan<2>(sm, lw, seg, sb.nsegp, sb.c1, sb.c2, sb.segm_w, sb.segs_w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -697,7 +716,7 @@ typedef UpperSmemT<PG_MAX_GROUPS> UpperSmem;
 template <int GPW, int NC, class SM>  // level-0 groups (of 64 segments) per wave: nseg <= 64 * PG_UPPER_WAVES * GPW
 __device__ __forceinline__ void upper_core(SM& sm, const double* __restrict__ segm, const uint64_t* __restrict__ segs, int stride,
                                            int nseg, double (&excl)[NC][GPW], double (&scale)[NC][GPW], double (&cmx)[NC][GPW],
-                                           double (&S)[NC]) {
+                                           double (&S)[NC], int nseg_l = 0x40000000, int rank_stride = 0) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n1 = (nseg + 63) >> 6;  // level-0 groups
     const int n2 = (n1 + 63) >> 6;    // <= 2 for nseg <= 8192
@@ -715,8 +734,9 @@ __device__ __forceinline__ void upper_core(SM& sm, const double* __restrict__ se
             mv[c][e] = -__builtin_inf();
             sv[c][e] = 0;
             if (b < nseg) {
-                mv[c][e] = segm[(size_t)c * stride + b];
-                sv[c][e] = segs[(size_t)c * stride + b];
+                const size_t at = (size_t)c * stride + (size_t)(b / nseg_l) * rank_stride + (b % nseg_l);  // (rank, cdf, local segment)
+                mv[c][e] = segm[at];
+                sv[c][e] = segs[at];
             }
             g[c] = __builtin_fmax(g[c], mv[c][e]);
         }
@@ -830,7 +850,8 @@ __device__ __forceinline__ void upper_core(SM& sm, const double* __restrict__ se
 // src/PGAS.py:122-124 / :225.  Three workgroup barriers; sm.cnt must be zero on entry (upper_core leaves it so).
 template <int GPW, class SM>
 __device__ __forceinline__ int cdf_count_block(SM& sm, const double (&ex)[GPW], const double (&sc)[GPW], const double (&cmx)[GPW],
-                                               int nseg, int N, double tau, const uint64_t* __restrict__ cbuf) {
+                                               int nseg, int N, double tau, const uint64_t* __restrict__ cbuf_local,
+                                               const uint64_t* const* cbuf_ranks = nullptr, int nseg_l = 0x40000000) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int c = 0;
 #pragma unroll
@@ -857,9 +878,10 @@ __device__ __forceinline__ int cdf_count_block(SM& sm, const double (&ex)[GPW], 
     const int64_t base = (int64_t)bs * PGAS_SEG;
     const int n = (N - base) < PGAS_SEG ? (int)(N - base) : PGAS_SEG;
     const double e0 = sm.par[0], s0 = sm.par[1], cy = sm.par[2];
+    const uint64_t* __restrict__ cseg = cbuf_ranks ? cbuf_ranks[bs / nseg_l] + (size_t)(bs % nseg_l) * PGAS_SEG : cbuf_local + base;
     int k = 0;
     for (int i = tid; i < n; i += PG_UPPER_THREADS) {
-        double num = e0 + s0 * (pgas_u64_to_double(cbuf[base + i]) * PGAS_FIX_INV);
+        double num = e0 + s0 * (pgas_u64_to_double(cseg[i]) * PGAS_FIX_INV);
         num = __builtin_fmax(num, cy);
         k += (num < tau) ? 1 : 0;
     }
@@ -871,16 +893,17 @@ __device__ __forceinline__ int cdf_count_block(SM& sm, const double (&ex)[GPW], 
 }
 
 template <int GPW>
-__global__ __launch_bounds__(PG_UPPER_THREADS) void k_upper(int N, int nseg, ScanBufs sb, int search_block, double u_search,
+__global__ __launch_bounds__(PG_UPPER_THREADS) void k_upper(int N, int nseg, ScanBufs sb, Peers pr, int search_block, double u_search,
                                                              int final_mode) {
+    // N, nseg: GLOBAL particle / segment counts (every rank of a sharded sweep runs this kernel on the gathered partials
+    // and gets identical results)
     __shared__ UpperSmem sm;
     const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nsegp = sb.nsegp;
-    double* __restrict__ excl = sb.excl + (size_t)w * nsegp;
-    double* __restrict__ scale = sb.scale + (size_t)w * nsegp;
-    double* __restrict__ cm = sb.cm + (size_t)w * nsegp;
+    double* __restrict__ excl = sb.excl + (size_t)w * sb.nsegp_g;
+    double* __restrict__ scale = sb.scale + (size_t)w * sb.nsegp_g;
+    double* __restrict__ cm = sb.cm + (size_t)w * sb.nsegp_g;
     double ex[1][GPW], sc[1][GPW], cmx[1][GPW], Sv[1];
-    upper_core<GPW, 1>(sm, sb.segm + (size_t)w * nsegp, sb.segs + (size_t)w * nsegp, 0, nseg, ex, sc, cmx, Sv);
+    upper_core<GPW, 1>(sm, sb.segm + (size_t)w * sb.nsegp, sb.segs + (size_t)w * sb.nsegp, 0, nseg, ex, sc, cmx, Sv, sb.nseg_l, sb.rank_stride);
     const double S = Sv[0];
 #pragma unroll
     for (int e = 0; e < GPW; ++e) {
@@ -898,7 +921,9 @@ __global__ __launch_bounds__(PG_UPPER_THREADS) void k_upper(int N, int nseg, Sca
     }
     if (w != search_block) return;
     int result = N - 1;
-    if (valid) result = cdf_count_block<GPW>(sm, ex[0], sc[0], cmx[0], nseg, N, u_search * S, w == 0 ? sb.c1 : sb.c2);
+    if (valid)
+        result = cdf_count_block<GPW>(sm, ex[0], sc[0], cmx[0], nseg, N, u_search * S, w == 0 ? sb.c1 : sb.c2,
+                                      pr.world > 1 ? (w == 0 ? pr.c1 : pr.c2) : nullptr, pr.nseg_l);
     if (tid == 0) {
         if (final_mode)
             sb.hdr->final_idx = result;
@@ -936,17 +961,25 @@ __device__ __forceinline__ double slot_tau(double u1, int64_t i, int N, double i
     return Ui * S;
 }
 
-__device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm, double u1, const ScanBufs& sb, int seg,
+// c1 data of GLOBAL source segment bs (this device's buffer, or a peer's through its xGMI mapping)
+__device__ __forceinline__ const uint64_t* c1_segment(const ScanBufs& sb, const Peers& pr, int bs) {
+    return pr.world > 1 ? pr.c1[bs / pr.nseg_l] + (size_t)(bs % pr.nseg_l) * PGAS_SEG : sb.c1 + (size_t)bs * PGAS_SEG;
+}
+
+// Search for the 1024 slots of local segment `seg`.  All indices that leave this function are GLOBAL particle indices;
+// md.p0 / md.Ng / md.nseg_g place the device's shard in the global particle range (single device: 0 / N / nseg).
+__device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm, double u1, const ScanBufs& sb, const Peers& pr, int seg,
                                                int32_t* __restrict__ anc_out, int (&anc_pm)[PG_PPT]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nseg = md.nseg, N = md.N;
+    const int nseg = md.nseg_g, N = md.Ng;
     const double S = sb.hdr->S[0];
     const bool valid = sb.hdr->valid[0] != 0;
     const bool pow2 = (N & (N - 1)) == 0;
     const double invN = 1.0 / (double)N;
     const double* __restrict__ cm = sb.cm;
-    const int64_t base_i = (int64_t)seg * PGAS_SEG;
-    const int nslots = (N - base_i) < PGAS_SEG ? (int)(N - base_i) : PGAS_SEG;
+    const int64_t loc_i = (int64_t)seg * PGAS_SEG;    // local index of slot 0 of this workgroup
+    const int64_t base_i = md.p0 + loc_i;             // its global index
+    const int nslots = (md.N - loc_i) < PGAS_SEG ? (int)(md.N - loc_i) : PGAS_SEG;
 
     double tau[PG_PPT];
     int a[PG_PPT];
@@ -980,18 +1013,23 @@ __device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm,
             b_hi += sm.red[1][v];
         }
         if (b_hi > nseg - 1) b_hi = nseg - 1;  // slots beyond the last segment keep a = N-1
-        // count the non-empty segments in [b_lo, b_hi] (empty ones -- running max unchanged -- own no slot)
+        // non-empty segments of [b_lo, b_hi] (running max moved), found by bisection jumps over cm: the next one after
+        // carry c is #{b : cm[b] <= c}.  Bounded work however long the run of empty segments is.
         int sb_idx[PG_STAGE];
         double g_carry = 0.0;
         int ns = 0, b = b_lo;
-        while (b <= b_hi && ns <= PG_STAGE) {
-            const double cy = b ? cm[b - 1] : 0.0, cb = cm[b];
-            if (cb > cy) {
-                if (ns == 0) g_carry = cy;
-                if (ns < PG_STAGE) sb_idx[ns] = b;
-                ++ns;
+        while (ns <= PG_STAGE) {
+            const double c0 = b ? cm[b - 1] : 0.0;
+            int lo = b, hi = nseg;  // first index >= b with cm > c0
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (cm[mid] <= c0) lo = mid + 1; else hi = mid;
             }
-            ++b;
+            if (lo > b_hi) break;
+            if (ns == 0) g_carry = c0;
+            if (ns < PG_STAGE) sb_idx[ns] = lo;
+            ++ns;
+            b = lo + 1;
         }
         if (ns > 0 && ns <= PG_STAGE) {
             // ---- common case: the workgroup's slots fall into at most PG_STAGE source segments.  Stage their
@@ -1005,7 +1043,7 @@ __device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm,
                     const double ex = sb.excl[bs], sc = sb.scale[bs], cy = bs ? cm[bs - 1] : 0.0;
                     const int64_t base_k = (int64_t)bs * PGAS_SEG;
                     const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
-                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(sb.c1 + base_k) + 2 * tid;
+                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(c1_segment(sb, pr, bs)) + 2 * tid;
                     const ulonglong2 c01 = src[0], c23 = src[1];
                     const int k0 = PG_PPT * tid;
                     if (k0 + 0 < n) v.x = __builtin_fmax(ex + sc * (pgas_u64_to_double(c01.x) * PGAS_FIX_INV), cy);
@@ -1057,7 +1095,7 @@ __device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm,
                     const double ex = sb.excl[bs], sc = sb.scale[bs], cy = bs ? cm[bs - 1] : 0.0;
                     const int64_t base_k = (int64_t)bs * PGAS_SEG;
                     const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
-                    const uint64_t* __restrict__ c = sb.c1 + base_k;
+                    const uint64_t* __restrict__ c = c1_segment(sb, pr, bs);
                     int lo = 0, hi = n;
                     while (lo < hi) {
                         const int mid = (lo + hi) >> 1;
@@ -1080,11 +1118,11 @@ __device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm,
 #pragma unroll
     for (int j = 0; j < PG_PPT; ++j) {
         sm.a[slot_of(tid, j)] = a[j];
-        if (base_i + slot_of(tid, j) < N) anc_out[base_i + slot_of(tid, j)] = a[j];
+        if (loc_i + slot_of(tid, j) < md.N) anc_out[loc_i + slot_of(tid, j)] = a[j];
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) anc_pm[r] = sm.a[r * PG_BLK + tid];  // ancestor of particle base_i + r*BLK + tid
+    for (int r = 0; r < PG_PPT; ++r) anc_pm[r] = sm.a[r * PG_BLK + tid];  // ancestor of local particle loc_i + r*BLK + tid
 }
 
 template <int NX>
@@ -1092,7 +1130,9 @@ __device__ __forceinline__ void back_slots(const DevModel& md, BackSmem& sm, int
                                            const double (&xcur)[PG_PPT][NX], int32_t* __restrict__ anc_out, double (&logw_new)[PG_PPT]) {
     const int tid = threadIdx.x;
     int anc[PG_PPT];
-    resample_slots(md, sm, u1, sb, seg, anc_out, anc);
+    Peers none;
+    none.world = 1;
+    resample_slots(md, sm, u1, sb, none, seg, anc_out, anc);
     const double* __restrict__ yt = md.y + (size_t)t * md.ny;
 #pragma unroll
     for (int r = 0; r < PG_PPT; ++r) {
@@ -1159,8 +1199,8 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
 #define PG_RS_SCAN 2    // scan step t's weights into sb_next; otherwise only emit logw_{t-1} (after the last step)
 __global__ __launch_bounds__(PG_BLK) void k_resample(DevModel md, int t, int mode, double u1_prev, const double* __restrict__ la_t,
                                                       const double* __restrict__ h_t, const double* __restrict__ ln_prev,
-                                                      ScanBufs sb_prev, ScanBufs sb_next, int32_t* __restrict__ anc_out,
-                                                      double* __restrict__ logw_out) {
+                                                      ScanBufs sb_prev, ScanBufs sb_next, Peers pr, int64_t laux_row_off,
+                                                      int32_t* __restrict__ anc_out, double* __restrict__ logw_out) {
     __shared__ union {
         BackSmem b;
         ScanSmem s;
@@ -1172,11 +1212,15 @@ __global__ __launch_bounds__(PG_BLK) void k_resample(DevModel md, int t, int mod
 #pragma unroll
         for (int r = 0; r < PG_PPT; ++r) lnv[r] = ln_prev[(size_t)seg * PGAS_SEG + r * PG_BLK + tid];
         int anc[PG_PPT];
-        resample_slots(md, sm.b, u1_prev, sb_prev, seg, anc_out, anc);
+        resample_slots(md, sm.b, u1_prev, sb_prev, pr, seg, anc_out, anc);
 #pragma unroll
         for (int r = 0; r < PG_PPT; ++r) {
             const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-            if (i < md.N) lwp[r] = lnv[r] - sb_prev.laux[anc[r]];
+            if (i < md.N) {
+                // log p(y_{t-1} | aux_{t-1}) of the ancestor: this device's row, or the owning peer's (src/PGAS.py:146)
+                const double la_anc = pr.world > 1 ? pr.laux[anc[r] / pr.Nl][laux_row_off + anc[r] % pr.Nl] : sb_prev.laux[anc[r]];
+                lwp[r] = lnv[r] - la_anc;
+            }
         }
         if (logw_out != nullptr) {
 #pragma unroll
@@ -1197,7 +1241,7 @@ __global__ __launch_bounds__(PG_BLK) void k_resample(DevModel md, int t, int mod
             lw[0][r] = valid ? l1 : -__builtin_inf();
             lw[1][r] = valid ? l1 + h_t[pi] : -__builtin_inf();
         }
-        segment_scan<2>(sm.s, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm, sb_next.segs);
+        segment_scan<2>(sm.s, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm_w, sb_next.segs_w);
     }
 }
 
@@ -1491,7 +1535,7 @@ __global__ __launch_bounds__(PG_BLK, 5) void k_resample_fast(DevModel md, int t,
             lw[1][r] = valid_p ? l1 + h_t[pi] : -__builtin_inf();
         }
         PG_STAMP(6);
-        segment_scan<2>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm, sb_next.segs);
+        segment_scan<2>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm_w, sb_next.segs_w);
     }
     PG_STAMP(7);
 }
@@ -1508,20 +1552,27 @@ __global__ __launch_bounds__(PG_BLK) void k_segscan(int N, const double* __restr
         const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
         lw[0][r] = i < N ? logw[i] : -__builtin_inf();
     }
-    segment_scan<1>(sm, lw, seg, sb.nsegp, sb.c1, nullptr, sb.segm, sb.segs);
+    segment_scan<1>(sm, lw, seg, sb.nsegp, sb.c1, nullptr, sb.segm_w, sb.segs_w);
 }
 
 // ------------------------------------------------------------------------------------------
 // k_backtrace: reconstruct_trajectory (src/Filtering.py:40-55), one lane chases the ancestors
 // ------------------------------------------------------------------------------------------
-__global__ void k_backtrace(int N, int T, int nx, const double* __restrict__ x_trace, const int32_t* __restrict__ anc_trace,
-                            const UpperHdr* __restrict__ hdr, double* __restrict__ traj) {
+__global__ void k_backtrace(int Nl, int T, int nx, const double* __restrict__ x_trace, const int32_t* __restrict__ anc_trace,
+                            Peers pr, const UpperHdr* __restrict__ hdr, double* __restrict__ traj) {
+    // b is a GLOBAL particle index; its row lives on rank b / Nl (single device: rank 0, Nl = N)
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     int64_t b = hdr->final_idx;
-    for (int k = 0; k < nx; ++k) traj[(size_t)(T - 1) * nx + k] = x_trace[((size_t)(T - 1) * N + b) * nx + k];
-    for (int i = T - 2; i >= 0; --i) {
-        b = anc_trace[(size_t)i * N + b];
-        for (int k = 0; k < nx; ++k) traj[(size_t)i * nx + k] = x_trace[((size_t)i * N + b) * nx + k];
+    for (int i = T - 1; i >= 0; --i) {
+        const int r = pr.world > 1 ? (int)(b / Nl) : 0;
+        const int64_t bl = b - (int64_t)r * Nl;
+        const double* __restrict__ xr = pr.world > 1 ? pr.x[r] : x_trace;
+        for (int k = 0; k < nx; ++k) traj[(size_t)i * nx + k] = xr[((size_t)i * Nl + bl) * nx + k];
+        if (i > 0) {
+            const int32_t* __restrict__ ar = pr.world > 1 ? pr.anc[r] : anc_trace;
+            // ancestor of particle b of time i, stored in row i-1 ... but row i-1 is indexed by the CHILD (time i) particle
+            b = ar[(size_t)(i - 1) * Nl + bl];
+        }
     }
 }
 

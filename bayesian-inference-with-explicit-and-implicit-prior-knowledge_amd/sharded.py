@@ -1,0 +1,139 @@
+"""Particle-sharded conditional-SMC sweep.
+
+The reference is a single process; this is the build's multi-GPU extension of
+``condSequentialMonteCarlo.__call__`` (src/PGAS.py:176-228).  Rank r owns particles
+[r N/G, (r+1) N/G); the conditioned particle N-1 lives on the last rank.  Per time step there is ONE
+collective: an all-gather of the per-segment softmax partials (2 x 2 x nseg_local 8-byte words per rank),
+after which every rank evaluates the identical cross-segment scan, so ancestors -- and the sampled
+trajectory -- do not depend on the number of ranks.  Ancestors that live on another rank are read
+through xGMI peer mappings of the scan buffers.
+
+Two groups implement the exchange:
+  * ``LocalGroup``  -- several shards in ONE process on one device (tests, single-GPU emulation);
+  * ``DistGroup``   -- one shard per process, torch.distributed (backend "nccl" = RCCL) + HIP IPC handles.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import random as prng
+from ._lib import Engine
+
+PH_INIT, PH_PROPAGATE, PH_RESAMPLE, PH_UPPER, PH_FINAL_SCAN, PH_FINAL_UPPER, PH_BACKTRACE = range(7)
+
+
+def shard_layout(N_global: int, world: int, seg: int = 1024):
+    """Particles per rank; every rank gets the same whole number of segments."""
+    if N_global % (world * seg):
+        raise ValueError(f"N = {N_global} must be a multiple of world * {seg} = {world * seg}")
+    return N_global // world
+
+
+class _Shard:
+    """One rank's engine plus torch views of the buffers that take part in the exchange."""
+
+    def __init__(self, eng: Engine, rank: int, world: int):
+        self.eng = eng
+        eng.shard_setup(rank, world)
+        self.ptrs, (self.nsegp, self.Nl, self.T) = eng.shard_buffers()
+        w = 2 * self.nsegp
+        self.segm_w = [eng.dev_tensor(self.ptrs[7 + i], (w,), torch.float64) for i in range(2)]
+        self.segs_w = [eng.dev_tensor(self.ptrs[9 + i], (w,), torch.int64) for i in range(2)]
+        self.segm_g = [eng.dev_tensor(self.ptrs[11 + i], (world * w,), torch.float64) for i in range(2)]
+        self.segs_g = [eng.dev_tensor(self.ptrs[13 + i], (world * w,), torch.int64) for i in range(2)]
+
+
+class LocalGroup:
+    """All shards live in this process (same device): pointers are shared directly, the all-gather is a copy."""
+
+    def __init__(self, shards):
+        self.shards = shards
+        for s in shards:
+            for peer, o in enumerate(shards):
+                s.eng.shard_set_peer(peer, o.ptrs[:7])
+
+    def all_gather(self, parity):
+        w = 2 * self.shards[0].nsegp
+        for s in self.shards:
+            for r, o in enumerate(self.shards):
+                s.segm_g[parity][r * w:(r + 1) * w].copy_(o.segm_w[parity])
+                s.segs_g[parity][r * w:(r + 1) * w].copy_(o.segs_w[parity])
+
+    def barrier(self):
+        torch.cuda.synchronize()
+
+
+class DistGroup:
+    """One shard per process.  torch.distributed carries the all-gather (RCCL for GPU tensors) and, once, the IPC handles."""
+
+    def __init__(self, shard, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group, self.shards = dist, group, [shard]
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        handles = [shard.eng.ipc_export(k) for k in range(7)]
+        everyone = [None] * world
+        dist.all_gather_object(everyone, handles, group=group)
+        for peer, hs in enumerate(everyone):
+            if peer == rank:
+                shard.eng.shard_set_peer(peer, shard.ptrs[:7])
+            else:
+                shard.eng.shard_set_peer(peer, [shard.eng.ipc_open(h) for h in hs])
+
+    def all_gather(self, parity):
+        s = self.shards[0]
+        self.dist.all_gather_into_tensor(s.segm_g[parity], s.segm_w[parity], group=self.group)
+        self.dist.all_gather_into_tensor(s.segs_g[parity], s.segs_w[parity], group=self.group)
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+def sharded_sweep(group, seed, ref, coeff_mat, error_cov, propagate_chunk=0):
+    """Run one sweep on every shard of `group`; returns the trajectory (T, nx) (identical on every rank)."""
+    shards = group.shards
+    T = shards[0].T
+    seed = prng.as_key(seed)
+    refs, trajs = [], []
+    for s in shards:
+        s.eng.set_params(coeff_mat, error_cov)
+        r = ref if isinstance(ref, torch.Tensor) else torch.as_tensor(np.asarray(ref, dtype=np.float64))
+        refs.append(r.to(device=s.eng.device, dtype=torch.float64).reshape(T, s.eng.nx).contiguous())
+        trajs.append(torch.empty((T, s.eng.nx), dtype=torch.float64, device=s.eng.device))
+    chunk = propagate_chunk if propagate_chunk > 0 else T
+    for s, r in zip(shards, refs):
+        s.eng.shard_run(PH_INIT, seed=seed, ref=r)
+        for t0 in range(1, T, chunk):
+            s.eng.shard_run(PH_PROPAGATE, t0, min(t0 + chunk, T), seed=seed, ref=r)
+    for t in range(1, T + 1):
+        for s in shards:
+            s.eng.shard_run(PH_RESAMPLE, t, seed=seed)
+        if t < T:
+            group.all_gather(t & 1)          # the one collective of the step
+            for s in shards:
+                s.eng.shard_run(PH_UPPER, t, seed=seed)
+    for s in shards:
+        s.eng.shard_run(PH_FINAL_SCAN, seed=seed)
+    group.all_gather(T & 1)
+    for s, tr in zip(shards, trajs):
+        s.eng.shard_run(PH_FINAL_UPPER, seed=seed)
+        s.eng.shard_run(PH_BACKTRACE, seed=seed, traj=tr)
+    group.barrier()                          # peers may still be reading this rank's traces
+    return trajs if len(trajs) > 1 else trajs[0]
+
+
+def make_local_group(world, N_global, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=None):
+    Nl = shard_layout(N_global, world)
+    shards = [_Shard(Engine(Nl, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=device), r, world)
+              for r in range(world)]
+    return LocalGroup(shards)
+
+
+def make_dist_group(N_global, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=None, group=None):
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    Nl = shard_layout(N_global, world)
+    shard = _Shard(Engine(Nl, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=device), rank, world)
+    return DistGroup(shard, group)

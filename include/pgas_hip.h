@@ -132,6 +132,27 @@ int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample
 #define PGAS_OPT_FORCE_SLOW_RESAMPLE 2 /* 1: always use the k_resample + k_upper pair (the path taken when N > 2^20 per device) */
 int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
 
+/* ---- particle-sharded sweep.  The reference is single-process; these entry points have no
+ * counterpart there.  One context per rank holds N_local = N_global / world particles (N_local a multiple of the
+ * segment size); the host drives the phases below and performs ONE collective per time step between RESAMPLE(t) and
+ * UPPER(t): an all-gather of the segment partials (pgas_shard_buffers: segm_w/segs_w -> segm_g/segs_g, RCCL through
+ * torch.distributed).  Ancestors that live on another rank are read through peer mappings (pgas_shard_set_peer;
+ * pgas_ipc_export / pgas_ipc_open carry the mappings between processes).  Results do not depend on `world`. */
+#define PGAS_SHARD_INIT 0        /* x_0                      (ref_dev)                         */
+#define PGAS_SHARD_PROPAGATE 1   /* time steps [t, t_aux)    (ref_dev)                         */
+#define PGAS_SHARD_RESAMPLE 2    /* launch t in [1,T]: resample step t-1 (t>1), scan step t (t<T) */
+#define PGAS_SHARD_UPPER 3       /* cross-segment scan of step t + reference ancestor, after the all-gather */
+#define PGAS_SHARD_FINAL_SCAN 4  /* softmax scan of logw_{T-1}; all-gather follows              */
+#define PGAS_SHARD_FINAL_UPPER 5 /* final index (src/PGAS.py:224-225)                           */
+#define PGAS_SHARD_BACKTRACE 6   /* trajectory (traj_dev), every rank computes the same one     */
+int pgas_shard_setup(pgas_ctx* ctx, int32_t rank, int32_t world);
+int pgas_shard_buffers(pgas_ctx* ctx, void** out15, int64_t* sizes3);
+int pgas_shard_set_peer(pgas_ctx* ctx, int32_t peer, const void* const* bufs7);
+int pgas_shard_run(pgas_ctx* ctx, int32_t phase, int32_t t, int32_t t_aux, uint64_t seed, const double* ref_dev, double* traj_dev,
+                   void* stream);
+int pgas_ipc_export(pgas_ctx* ctx, int32_t which, void* handle64);
+int pgas_ipc_open(pgas_ctx* ctx, const void* handle64, void** ptr);
+
 /* Sufficient statistics of PGAS.sample_params (src/PGAS.py:294-303, BI:53-61) without the prior:
  * traj_dev (T,nx) -> T0 (M,nx), T1 (M,M) [fp64 MFMA SYRK], T2 (nx,nx); T3 = T-1.
  * Pairs traj[:-1] with inputs[:-1] (quirk Q3). */

@@ -179,3 +179,25 @@ def test_error_reporting():
     with pytest.raises(TypeError):
         pgas_amd.condSequentialMonteCarlo(64, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
                                           lambda o, s, i: 0.0, pb.basis_fcn)
+
+
+@pytest.mark.parametrize("name,N,world", [("smo", 4096, 2), ("smo", 8192, 4), ("smo", 65536, 8), ("toy", 2048, 2), ("emps", 2048, 2)])
+def test_sharded_sweep_bit_exact_and_independent_of_world(name, N, world):
+    """Particle-sharded sweep (several shards emulated in one process on one device): the trajectory and the traces are the
+    single-device / oracle ones bit for bit, whatever the number of shards."""
+    from pgas_amd import sharded
+
+    pb = _problems()[name]()
+    A, S = experiments.initial_params(pb)
+    cm = canon_model(pb, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    trajo, Xo, ANCo, lwo = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
+    grp = sharded.make_local_group(world, N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+    trajs = sharded.sharded_sweep(grp, SEED, pb.X_true, A, S, propagate_chunk=5)
+    Nl = N // world
+    for r, (s, tr) in enumerate(zip(grp.shards, trajs)):
+        _eq(tr, trajo.reshape(tr.shape), f"trajectory on rank {r}")
+        X, ANC, LW, _ = s.eng.traces()
+        _eq(X, Xo[:, r * Nl:(r + 1) * Nl], f"state_trace shard {r}")
+        _eq(ANC[: pb.T - 1], ANCo[:, r * Nl:(r + 1) * Nl], f"ancestor_trace shard {r}")
+        _eq(LW, lwo[r * Nl:(r + 1) * Nl], f"log_weights shard {r}")
