@@ -83,10 +83,18 @@ class DistGroup:
 
     def all_gather(self, parity):
         s = self.shards[0]
+        if self.dist.get_backend(self.group) == "gloo":
+            # development / test path (several ranks on one GPU, where RCCL refuses duplicate devices): stage through the host
+            for dst, src in ((s.segm_g[parity], s.segm_w[parity]), (s.segs_g[parity], s.segs_w[parity])):
+                parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(self.dist.get_world_size(self.group))]
+                self.dist.all_gather(parts, src.cpu(), group=self.group)
+                dst.copy_(torch.cat(parts))
+            return
         self.dist.all_gather_into_tensor(s.segm_g[parity], s.segm_w[parity], group=self.group)
         self.dist.all_gather_into_tensor(s.segs_g[parity], s.segs_w[parity], group=self.group)
 
     def barrier(self):
+        torch.cuda.synchronize()
         self.dist.barrier(group=self.group)
 
 

@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--chunk", type=int, default=-1, help="time steps per k_propagate launch (engine default if < 0)")
     ap.add_argument("--no-overlap", action="store_true", help="run the weight recursion on the caller's stream (no concurrency)")
+    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
+                    help="multi-GPU partition: independent chains, one per GPU (default; BASELINE config 5) or ONE sweep whose "
+                         "--particles x G particles are sharded over the G ranks (RCCL all-gather per step + xGMI peer reads; config 4)")
     args = ap.parse_args()
 
     import torch
@@ -82,7 +85,8 @@ def main():
     from pgas_amd import experiments
 
     N, T = args.particles, args.T
-    seed = 12345678 + rank  # independent chains differ by seed (BASELINE config 5 convention: 12345678 + g)
+    sharded_mode = args.mode == "sharded" and world > 1
+    seed = 12345678 + (0 if sharded_mode else rank)  # independent chains differ by seed (BASELINE config 5 convention: 12345678 + g)
     pb = experiments.smo_pgas(T=T)
     pg = pgas_amd.PGAS(N, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior,
                        pb.basis_fcn, device=f"cuda:{local_rank}")
@@ -101,13 +105,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    grp = None
+    if sharded_mode:
+        from pgas_amd import sharded
+
+        # every rank must use the same (A, S): take rank 0's
+        dist.broadcast(A, src=0)
+        dist.broadcast(S, src=0)
+        grp = sharded.make_dist_group(N * world, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn,
+                                      pb.basis_fcn, device=f"cuda:{local_rank}")
+        args.no_profile = True
+
+    def one_sweep(sd):
+        if grp is not None:
+            sharded.sharded_sweep(grp, sd, ref, A, S, propagate_chunk=64)
+        else:
+            pg.cSMC(sd, ref, A, S)
+
     for w in range(args.warmup):
-        pg.cSMC(seed + 1000 + w, ref, A, S)
+        one_sweep(seed + 1000 + w)
     barrier()
     t0 = time.perf_counter()
     prof_n, prof_ms, prop_n, prop_ms = 0, 0.0, 0, 0.0
     for k in range(args.steps):
-        pg.cSMC(seed + k, ref, A, S)
+        one_sweep(seed + k)
         if not args.no_profile:
             n, ms, pn, pm = eng.profile()   # synchronises this sweep; the events sit inside the timed region
             prof_n += n
@@ -131,8 +152,10 @@ def main():
             "workload": f"SingleMassOscillator PGAS sweep, N={N} particles/GPU, T={T}, nx=2, M=41 Hilbert basis, fp64 "
                         f"(BASELINE.json configs[1])",
             "particles_per_gpu": N, "T": T,
-            "parallelism": "1 GPU" if world == 1 else f"{world} independent chains, one per GPU, no data-path collective (replicas; "
-                                                       f"particle-sharded sweep is DESIGN.md section 7)",
+            "parallelism": "1 GPU" if world == 1 else (
+                f"one sweep of {N * world} particles sharded over {world} GPUs: RCCL all-gather of segment partials per step + xGMI peer reads"
+                if sharded_mode else
+                f"{world} independent chains, one per GPU, no data-path collective (replicas; --mode sharded runs the particle-sharded sweep)"),
         },
     }
     if rank == 0:

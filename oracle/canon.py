@@ -60,6 +60,8 @@ def lib():
         L.oc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int, dp]
         L.oc_u64_to_double.restype = C.c_double
         L.oc_u64_to_double.argtypes = [C.c_uint64]
+        L.oc_segment_partials.argtypes = [dp, C.c_int64, dp, u64p, u64p]
+        L.oc_resample_range.argtypes = [C.c_int32, dp, u64p, u64p, C.c_int64, C.c_double, C.c_int64, C.c_int64, ip]
         L.oc_seg.restype = C.c_int32
         _lib = L
     return _lib
@@ -115,6 +117,26 @@ def normals(seed, stream, t, p0, n_particles, n):
     z = np.empty((n_particles, n))
     lib().oc_normals(seed, stream, t, p0, n_particles, n, _dp(z))
     return z
+
+
+def segment_partials(lw):
+    """Per-segment softmax partials of a log-weight vector: (segm (nseg,), segs (nseg,) uint64, c (n,) uint64)."""
+    lw = _f64(lw)
+    n = lw.size
+    nseg = (n + 1023) // 1024
+    segm, segs, c = np.empty(nseg), np.empty(nseg, np.uint64), np.empty(n, np.uint64)
+    u64p = C.POINTER(C.c_uint64)
+    lib().oc_segment_partials(_dp(lw), n, _dp(segm), segs.ctypes.data_as(u64p), c.ctypes.data_as(u64p))
+    return segm, segs, c
+
+
+def resample_range(segm, segs, c, N, u, i0, i1):
+    """Ancestors of slots [i0, i1) given ALL segments' partials and cumsums (what a rank holds after the all-gather)."""
+    segm, segs, c = _f64(segm), np.ascontiguousarray(segs, np.uint64), np.ascontiguousarray(c, np.uint64)
+    anc = np.empty(i1 - i0, np.int32)
+    u64p = C.POINTER(C.c_uint64)
+    lib().oc_resample_range(len(segm), _dp(segm), segs.ctypes.data_as(u64p), c.ctypes.data_as(u64p), N, u, i0, i1, _ip(anc))
+    return anc
 
 
 # ---------------------------------------------------------------- model + algorithm

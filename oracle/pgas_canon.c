@@ -337,6 +337,32 @@ static int64_t cdf_count(const upper_t* U, const uint64_t* c, int64_t N, double 
     return base + cnt;
 }
 
+/* ---- pieces of the resampling machinery, exported for the sharded-decomposition test (tests/test_sharded_cpu.py):
+ * per-segment partials, and the search of a slot range given ALL segments' partials (as they are after an all-gather). */
+EXPORT void oc_segment_partials(const double* lw, int64_t n, double* segm, uint64_t* segs, uint64_t* c) {
+    int nseg = (int)((n + PGAS_SEG - 1) / PGAS_SEG);
+    for (int b = 0; b < nseg; ++b) {
+        int64_t base = (int64_t)b * PGAS_SEG;
+        int len = n - base < PGAS_SEG ? (int)(n - base) : PGAS_SEG;
+        segment_scan(lw + base, len, &segm[b], c + base, &segs[b]);
+    }
+}
+EXPORT void oc_resample_range(int32_t nseg, const double* segm, const uint64_t* segs, const uint64_t* c, int64_t N, double u,
+                              int64_t i0, int64_t i1, int32_t* anc) {
+    upper_t U;
+    upper_build(&U, nseg, segm, segs);
+    for (int64_t i = i0; i < i1; ++i) {
+        int64_t a = i;
+        if (U.valid) {
+            double Ui = (u + (double)i) / (double)N;
+            a = cdf_count(&U, c, N, Ui * U.S);
+            if (a > N - 1) a = N - 1;
+        }
+        anc[i - i0] = (int32_t)a;
+    }
+    upper_free(&U);
+}
+
 /* ------------------------------------------------------------------------------- step -- */
 /*
  * One conditional-SMC step, reference src/PGAS.py:79-153 (quirks Q1, Q3, Q4, Q6 reproduced).
