@@ -4,6 +4,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -12,6 +13,9 @@
 #include "pgas_kernels.hip.h"
 #include "pgas_suffstats.hip.h"
 
+#ifndef PG_W28
+#define PG_W28 2
+#endif
 namespace {
 
 thread_local std::string g_create_error;
@@ -48,7 +52,7 @@ bool pick_variant(int nx, int D, int jin_needed, Variant* v, int* JP) {
         if (D == 2) *v = jp == 8 ? make_variant<1, 2, 8, 2, 2>() : jp == 12 ? make_variant<1, 2, 12, 2, 2>() : make_variant<1, 2, 16, 2, 2>();
         else *v = jp == 8 ? make_variant<1, 3, 8, 2, 2>() : jp == 12 ? make_variant<1, 3, 12, 2, 2>() : make_variant<1, 3, 16, 2, 2>();
     } else {
-        if (D == 2) *v = jp == 8 ? make_variant<2, 2, 8, 2, 2>() : jp == 12 ? make_variant<2, 2, 12, 2, 2>() : make_variant<2, 2, 16, 2, 2>();
+        if (D == 2) *v = jp == 8 ? make_variant<2, 2, 8, 2, PG_W28>() : jp == 12 ? make_variant<2, 2, 12, 2, 2>() : make_variant<2, 2, 16, 2, 2>();
         else *v = jp == 8 ? make_variant<2, 3, 8, 2, 2>() : jp == 12 ? make_variant<2, 3, 12, 2, 2>() : make_variant<2, 3, 16, 2, 2>();
     }
     return true;
@@ -96,7 +100,7 @@ struct pgas_ctx {
     unsigned launch_tag = 0;    // unique id per k_resample_fast launch (hand-off word tag)
     int force_slow = 0;         // 1: never use k_resample_fast (test hook for the k_resample + k_upper path)
     int overlap = 1;            // 1: run the weight recursion on an internal stream concurrently with k_propagate
-    hipStream_t sB = nullptr;   // internal high-priority stream of the weight recursion
+    hipStream_t sB = nullptr;   // internal stream of the weight recursion
     std::vector<hipEvent_t> ev_chunk;  // "k_propagate chunk c done" events
     hipEvent_t ev_start = nullptr, ev_done = nullptr;
     // suff-stat scratch
@@ -411,16 +415,17 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
             }
         }
         // pipeline A (caller's stream): every particle through all time steps; independent of the weights (quirk Q1).
-        // pipeline B (internal high-priority stream when overlap is on): the weight recursion, gated chunk by chunk on
+        // pipeline B (internal stream when overlap is on): the weight recursion, gated chunk by chunk on
         // pipeline A by events, so that its latency-bound launches run underneath k_propagate's arithmetic.
-        const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 2 : T);
+        const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 1 : T);
         const int nchunk = (T - 1 + chunk - 1) / chunk;
         hipStream_t sb_stream = st;
         if (c->overlap) {
             if (!c->sB) {
                 int lo = 0, hi = 0;
                 HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, hi));
+                // measured (tools/overlap_exp.sh): the chain stream at LOW priority and one-step k_propagate launches overlap best
+                HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, lo));
                 HIPCHK(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
                 HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
             }

@@ -128,7 +128,7 @@ int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample
 
 /* Tuning / test knobs.  PGAS_OPT_PROPAGATE_CHUNK: time steps per k_propagate launch (0 = the whole sweep in one launch). */
 #define PGAS_OPT_PROPAGATE_CHUNK 1
-#define PGAS_OPT_OVERLAP 3 /* 1 (default): weight recursion on an internal high-priority stream, concurrent with k_propagate */
+#define PGAS_OPT_OVERLAP 3 /* 1 (default): weight recursion on an internal stream, concurrent with k_propagate */
 #define PGAS_OPT_FORCE_SLOW_RESAMPLE 2 /* 1: always use the k_resample + k_upper pair (the path taken when N > 2^20 per device) */
 int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
 
