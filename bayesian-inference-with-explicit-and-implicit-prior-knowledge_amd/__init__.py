@@ -16,6 +16,7 @@ from .BayesianInferrence import (  # noqa: F401
     prior_mniw_mean,
 )
 from .descriptors import BasisMap, GaussianLikelihood, HilbertBasis  # noqa: F401
+from .Filtering import reconstruct_trajectory, systematic_SISR  # noqa: F401
 from .PGAS import PGAS, condSequentialMonteCarlo  # noqa: F401
 
 __all__ = [
@@ -30,4 +31,6 @@ __all__ = [
     "prior_mniw_calcStatistics",
     "prior_mniw_mean",
     "random",
+    "systematic_SISR",
+    "reconstruct_trajectory",
 ]

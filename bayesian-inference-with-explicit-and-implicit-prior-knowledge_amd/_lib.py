@@ -36,6 +36,7 @@ EXPORTS = [
     "pgas_create", "pgas_destroy", "pgas_last_error", "pgas_segment_size", "pgas_set_params", "pgas_basis_eval",
     "pgas_aux_states", "pgas_init_state", "pgas_step", "pgas_sweep", "pgas_get_traces", "pgas_last_final_index",
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
+    "pgas_systematic_resample", "pgas_reconstruct_trajectory",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
 ]
 
@@ -82,6 +83,10 @@ def load():
     L.pgas_get_profile.argtypes = [vp, C.POINTER(i64), C.POINTER(C.c_double), C.POINTER(i64), C.POINTER(C.c_double), vp]
     L.pgas_set_option.restype = C.c_int
     L.pgas_set_option.argtypes = [vp, i32, i64]
+    L.pgas_systematic_resample.restype = C.c_int
+    L.pgas_systematic_resample.argtypes = [vp, C.c_double, vp, vp, vp]
+    L.pgas_reconstruct_trajectory.restype = C.c_int
+    L.pgas_reconstruct_trajectory.argtypes = [vp, vp, vp, i32, i32, i64, vp, vp]
     L.pgas_shard_setup.restype = C.c_int
     L.pgas_shard_setup.argtypes = [vp, i32, i32]
     L.pgas_shard_buffers.restype = C.c_int
@@ -256,6 +261,44 @@ class Engine:
 
     def set_option(self, option, value):
         self._chk(self.lib.pgas_set_option(self._h, int(option), int(value)), "pgas_set_option")
+
+    # -------------------------------------------------------------- src/Filtering.py free functions
+    _utility = {}
+
+    @classmethod
+    def utility(cls, N, device=None):
+        """A context that only serves pgas_systematic_resample / pgas_reconstruct_trajectory for N particles (trivial model)."""
+        from .descriptors import BasisMap, GaussianLikelihood, HilbertBasis
+
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        key = (dev.index or 0, int(N))
+        if key not in cls._utility:
+            basis = HilbertBasis(np.array([[1]], dtype=np.int32), np.array([[-1.0, 1.0]]))
+            cls._utility[key] = cls(int(N), np.zeros((1, 1)), None, np.zeros(1), np.eye(1), GaussianLikelihood(np.eye(1), np.eye(1)),
+                                    BasisMap(basis, [0]), device=dev)
+        return cls._utility[key]
+
+    def systematic_resample(self, u, logw):
+        lw = self._dev(logw, shape=(self.N,))
+        idx = torch.empty(self.N, dtype=torch.int32, device=self.device)
+        self._chk(self.lib.pgas_systematic_resample(self._h, float(u), lw.data_ptr(), idx.data_ptr(), self._stream()), "pgas_systematic_resample")
+        return idx
+
+    def reconstruct_trajectory(self, particles, ancestry, idx):
+        P = particles if isinstance(particles, torch.Tensor) else torch.as_tensor(np.asarray(particles, dtype=np.float64))
+        P = P.to(device=self.device, dtype=torch.float64)
+        if P.dim() == 2:
+            P = P.unsqueeze(-1)
+        P = P.contiguous()
+        T, N, nx = P.shape
+        if N != self.N:
+            raise ValueError(f"particle count {N} does not match the context ({self.N})")
+        A = ancestry if isinstance(ancestry, torch.Tensor) else torch.as_tensor(np.asarray(ancestry))
+        A = A.to(device=self.device, dtype=torch.int32).contiguous()   # the reference stores float64 indices (Q2)
+        traj = torch.empty((T, nx), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.pgas_reconstruct_trajectory(self._h, P.data_ptr(), A.data_ptr(), T, nx, int(idx), traj.data_ptr(), self._stream()),
+                  "pgas_reconstruct_trajectory")
+        return traj
 
     # -------------------------------------------------------------- particle sharding (pgas_amd/sharded.py)
     def shard_setup(self, rank, world):

@@ -100,6 +100,8 @@ struct pgas_ctx {
     unsigned launch_tag = 0;    // unique id per k_resample_fast launch (hand-off word tag)
     int force_slow = 0;         // 1: never use k_resample_fast (test hook for the k_resample + k_upper path)
     int overlap = 1;            // 1: run the weight recursion on an internal stream concurrently with k_propagate
+    int prop_lds = 0;   // dynamic LDS reserved per k_propagate workgroup when overlapping: caps it at two workgroups per CU so
+                                // that two k_resample_fast workgroups (25.5 KB LDS, 96 VGPRs) always fit beside them
     hipStream_t sB = nullptr;   // internal stream of the weight recursion
     std::vector<hipEvent_t> ev_chunk;  // "k_propagate chunk c done" events
     hipEvent_t ev_start = nullptr, ev_done = nullptr;
@@ -450,7 +452,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
                 }
                 HIPCHK(c, hipEventRecord(c->evp[c->evp_used], st));
             }
-            hipLaunchKernelGGL(c->var.prop, grid, blk, 0, st, md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
+            hipLaunchKernelGGL(c->var.prop, grid, blk, c->overlap ? c->prop_lds : 0, st, md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
             KCHK(c, "k_propagate");
             if (c->profiling) { HIPCHK(c, hipEventRecord(c->evp[c->evp_used + 1], st)); c->evp_used += 2; }
             if (c->overlap) {
@@ -548,6 +550,11 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         c->overlap = value ? 1 : 0;
         return PGAS_OK;
     }
+    if (option == PGAS_OPT_PROPAGATE_LDS) {
+        if (value < 0 || value > 160 * 1024) FAIL(c, PGAS_E_ARG, "pgas_set_option: LDS bytes out of range");
+        c->prop_lds = (int)value;
+        return PGAS_OK;
+    }
     FAIL(c, PGAS_E_ARG, "pgas_set_option: unknown option %d", option);
 }
 
@@ -581,6 +588,37 @@ int pgas_debug_stamps(unsigned long long* out /* 2048*16 */) {
 }
 #endif
 
+
+/* systematic_SISR (src/Filtering.py:6-37) on log-weights: idx[i] = first k with W_k >= (u + i)/N, W the canonical CDF of
+ * softmax(logw).  Uses the context's scan scratch; logw_dev (N), idx_dev (N) int32. */
+int pgas_systematic_resample(pgas_ctx* c, double u, const double* logw_dev, int32_t* idx_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!logw_dev || !idx_dev || !(u >= 0.0 && u < 1.0)) FAIL(c, PGAS_E_ARG, "pgas_systematic_resample: bad argument");
+    if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_systematic_resample: not available on a shard context");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    const DevModel& md = c->md;
+    hipLaunchKernelGGL(k_segscan, dim3(md.nseg), dim3(PG_BLK), 0, st, md.N, logw_dev, c->sb[0]);
+    KCHK(c, "k_segscan");
+    int rc = launch_upper(c, c->sb[0], 1, -1, 0.0, 0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_systematic, dim3(md.nseg), dim3(PG_BLK), 0, st, md, u, c->sb[0], idx_dev);
+    KCHK(c, "k_systematic");
+    return PGAS_OK;
+}
+
+/* reconstruct_trajectory (src/Filtering.py:40-55): x_dev (T,N,nx), anc_dev (T-1,N) int32 with anc[i][j] = index at time i of the
+ * ancestor of particle j of time i+1, idx = index at time T-1; traj_dev (T,nx) out.  T and nx are passed explicitly, N is the context's. */
+int pgas_reconstruct_trajectory(pgas_ctx* c, const double* x_dev, const int32_t* anc_dev, int32_t T, int32_t nx, int64_t idx,
+                                double* traj_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!x_dev || !traj_dev || T < 1 || nx < 1 || idx < 0 || idx >= c->md.N || (T > 1 && !anc_dev))
+        FAIL(c, PGAS_E_ARG, "pgas_reconstruct_trajectory: bad argument");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_backtrace_idx, dim3(1), dim3(64), 0, (hipStream_t)stream, c->md.N, T, nx, x_dev, anc_dev, idx, traj_dev);
+    KCHK(c, "k_backtrace_idx");
+    return PGAS_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Particle-sharded sweep (one context per rank, each owning N_local = N_global / world particles).

@@ -969,7 +969,7 @@ __device__ __forceinline__ const uint64_t* c1_segment(const ScanBufs& sb, const 
 // Search for the 1024 slots of local segment `seg`.  All indices that leave this function are GLOBAL particle indices;
 // md.p0 / md.Ng / md.nseg_g place the device's shard in the global particle range (single device: 0 / N / nseg).
 __device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm, double u1, const ScanBufs& sb, const Peers& pr, int seg,
-                                               int32_t* __restrict__ anc_out, int (&anc_pm)[PG_PPT]) {
+                                               int32_t* __restrict__ anc_out, int (&anc_pm)[PG_PPT], bool conditioned = true) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nseg = md.nseg_g, N = md.Ng;
     const double S = sb.hdr->S[0];
@@ -1112,7 +1112,7 @@ __device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm,
 #pragma unroll
     for (int j = 0; j < PG_PPT; ++j) {
         const int64_t i = base_i + slot_of(tid, j);
-        if (i == N - 1) a[j] = sb.hdr->ref_idx;  // src/PGAS.py:127
+        if (conditioned && i == N - 1) a[j] = sb.hdr->ref_idx;  // src/PGAS.py:127
     }
     __syncthreads();
 #pragma unroll
@@ -1265,8 +1265,8 @@ struct FastSmem {
             double excl[PG_FAST_NSEG], scale[PG_FAST_NSEG];
         } tab;
         ScanSmem scan;
+        int a[PGAS_SEG];  // ancestors, slot-major -> particle-major exchange (after the search is done with `num`)
     } u;
-    int a[PGAS_SEG];
     // candidate source segments of this workgroup (index, excl, scale, carry): copied out of `tab` before staging reuses it
     int cand_b[PG_FGROUPS * PG_FSTAGE];
     double cand_ex[PG_FGROUPS * PG_FSTAGE], cand_sc[PG_FGROUPS * PG_FSTAGE], cand_cy[PG_FGROUPS * PG_FSTAGE];
@@ -1505,14 +1505,14 @@ __global__ __launch_bounds__(PG_BLK, 5) void k_resample_fast(DevModel md, int t,
         __syncthreads();
     #pragma unroll
         for (int j = 0; j < PG_PPT; ++j) {
-            sm.a[slot_of(tid, j)] = a[j];
+            sm.u.a[slot_of(tid, j)] = a[j];
             if (base_i + slot_of(tid, j) < N) anc_out[base_i + slot_of(tid, j)] = a[j];
         }
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < PG_PPT; ++r) {
             const int64_t i = base_i + r * PG_BLK + tid;
-            if (i < N) lwp[r] = lnv[r] - sb_prev.laux[sm.a[r * PG_BLK + tid]];
+            if (i < N) lwp[r] = lnv[r] - sb_prev.laux[sm.u.a[r * PG_BLK + tid]];
         }
         PG_STAMP(5);
         if (logw_out != nullptr) {
@@ -1573,6 +1573,28 @@ __global__ void k_backtrace(int Nl, int T, int nx, const double* __restrict__ x_
             // ancestor of particle b of time i, stored in row i-1 ... but row i-1 is indexed by the CHILD (time i) particle
             b = ar[(size_t)(i - 1) * Nl + bl];
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Standalone Filtering entry points (reference src/Filtering.py): systematic_SISR on a weight vector whose softmax scan
+// (k_segscan + k_upper) is already in sb, and reconstruct_trajectory from caller-owned traces.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PG_BLK) void k_systematic(DevModel md, double u, ScanBufs sb, int32_t* __restrict__ idx_out) {
+    __shared__ BackSmem sm;
+    int anc[PG_PPT];
+    Peers none;
+    none.world = 1;
+    resample_slots(md, sm, u, sb, none, blockIdx.x, idx_out, anc, false);
+}
+
+__global__ void k_backtrace_idx(int N, int T, int nx, const double* __restrict__ x_trace, const int32_t* __restrict__ anc_trace,
+                                int64_t idx, double* __restrict__ traj) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t b = idx;
+    for (int i = T - 1; i >= 0; --i) {
+        for (int k = 0; k < nx; ++k) traj[(size_t)i * nx + k] = x_trace[((size_t)i * N + b) * nx + k];
+        if (i > 0) b = anc_trace[(size_t)(i - 1) * N + b];
     }
 }
 

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--chunk", type=int, default=-1, help="time steps per k_propagate launch (engine default if < 0)")
     ap.add_argument("--no-overlap", action="store_true", help="run the weight recursion on the caller's stream (no concurrency)")
+    ap.add_argument("--prop-lds", type=int, default=-1, help="LDS bytes reserved per k_propagate workgroup while overlapping (engine default if < 0)")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="multi-GPU partition: independent chains, one per GPU (default; BASELINE config 5) or ONE sweep whose "
                          "--particles x G particles are sharded over the G ranks (RCCL all-gather per step + xGMI peer reads; config 4)")
@@ -99,6 +100,8 @@ def main():
         eng.set_option(1, args.chunk)      # PGAS_OPT_PROPAGATE_CHUNK
     if args.no_overlap:
         eng.set_option(3, 0)               # PGAS_OPT_OVERLAP
+    if args.prop_lds >= 0:
+        eng.set_option(4, args.prop_lds)   # PGAS_OPT_PROPAGATE_LDS
 
     def barrier():
         if world > 1:

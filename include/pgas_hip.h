@@ -128,9 +128,17 @@ int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample
 
 /* Tuning / test knobs.  PGAS_OPT_PROPAGATE_CHUNK: time steps per k_propagate launch (0 = the whole sweep in one launch). */
 #define PGAS_OPT_PROPAGATE_CHUNK 1
+#define PGAS_OPT_PROPAGATE_LDS 4 /* bytes of LDS reserved per k_propagate workgroup while overlapping (occupancy cap) */
 #define PGAS_OPT_OVERLAP 3 /* 1 (default): weight recursion on an internal stream, concurrent with k_propagate */
 #define PGAS_OPT_FORCE_SLOW_RESAMPLE 2 /* 1: always use the k_resample + k_upper pair (the path taken when N > 2^20 per device) */
 int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
+
+/* Free functions of src/Filtering.py on the device.  systematic_SISR(key, w) (:6-37): u = the uniform the reference draws
+ * from `key` (:19); weights are passed as log-weights (log 0 = -inf allowed, negative weights have no logarithm: the
+ * reference's clip at :23 is the caller's clamp).  reconstruct_trajectory(Particles, ancestry, idx) (:40-55). */
+int pgas_systematic_resample(pgas_ctx* ctx, double u, const double* logw_dev, int32_t* idx_dev, void* stream);
+int pgas_reconstruct_trajectory(pgas_ctx* ctx, const double* x_dev, const int32_t* anc_dev, int32_t T, int32_t nx, int64_t idx,
+                                double* traj_dev, void* stream);
 
 /* ---- particle-sharded sweep.  The reference is single-process; these entry points have no
  * counterpart there.  One context per rank holds N_local = N_global / world particles (N_local a multiple of the

@@ -201,3 +201,59 @@ def test_sharded_sweep_bit_exact_and_independent_of_world(name, N, world):
         _eq(X, Xo[:, r * Nl:(r + 1) * Nl], f"state_trace shard {r}")
         _eq(ANC[: pb.T - 1], ANCo[:, r * Nl:(r + 1) * Nl], f"ancestor_trace shard {r}")
         _eq(LW, lwo[r * Nl:(r + 1) * Nl], f"log_weights shard {r}")
+
+
+def test_filtering_free_functions():
+    """src/Filtering.py mirror: systematic_SISR KATs and reconstruct_trajectory on a hand-built ancestry."""
+    from oracle import pgas_numpy as o
+    from pgas_amd import random as prng
+    from pgas_amd.Filtering import STREAM_SISR
+
+    key = 7
+    u = float(prng.uniform(key, 1, stream=STREAM_SISR)[0])
+    w = np.array([0.1, 0.2, 0.3, 0.4])
+    assert pgas_amd.systematic_SISR(key, w).cpu().numpy().tolist() == o.systematic_SISR(u, w).tolist()
+    assert pgas_amd.systematic_SISR(key, np.zeros(9)).cpu().numpy().tolist() == list(range(9))          # Filtering.py:25
+    assert pgas_amd.systematic_SISR(key, [-1.0, 0.5, 0.5]).cpu().numpy().tolist() == o.systematic_SISR(u, [0.0, 0.5, 0.5]).tolist()
+    rng = np.random.default_rng(3)
+    for N in (1000, 5000, 70001):
+        w = rng.random(N) ** 4
+        got = pgas_amd.systematic_SISR(key, w).cpu().numpy()
+        ref = o.systematic_SISR(u, w)
+        assert np.all(np.diff(got) >= 0)
+        bad = np.nonzero(got != ref)[0]
+        W = np.cumsum(w / w.sum())
+        U = (u + np.arange(N)) / N
+        assert all(abs(W[min(got[i], ref[i])] - U[i]) < 1e-9 for i in bad), "indices differ away from a CDF tie"
+        assert np.all(np.abs(np.bincount(got, minlength=N) - N * w / w.sum()) <= 1 + 1e-6)
+    P = np.arange(12, dtype=float).reshape(4, 3)
+    anc = np.array([[2, 0, 1], [1, 1, 0], [0, 2, 2]], dtype=float)   # float64 like the reference's trace (Q2)
+    assert pgas_amd.reconstruct_trajectory(P[:, :, None], anc, 1).cpu().numpy().tolist() == [2.0, 3.0, 8.0, 10.0]
+    X = rng.standard_normal((6, 500, 2))
+    A = rng.integers(0, 500, (5, 500))
+    assert np.array_equal(pgas_amd.reconstruct_trajectory(X, A, 123).cpu().numpy(), o.reconstruct_trajectory(X, A, 123))
+
+
+@pytest.mark.parametrize("N,T", [(1, 5), (2, 4), (63, 3), (1024, 1), (300, 2)])
+def test_tiny_sizes(N, T):
+    """Edge sizes: a single particle (only the conditioned one), fewer particles than a wave, T = 1 (no step at all), T = 2."""
+    pb = experiments.smo_pgas(T=max(T, 2))
+    if T == 1:
+        pb.observations, pb.inputs, pb.X_true = pb.observations[:1], pb.inputs[:1], pb.X_true[:1]
+    A, S = experiments.initial_params(experiments.smo_pgas(T=8))
+    cm = canon_model(pb, N)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn)
+    LS, LSinv, cS = cm.chol_parts(S)
+    traj = csmc(SEED, pb.X_true, A, S)
+    if T == 1:
+        x0 = cm.init_state(SEED, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov), pb.X_true[0])
+        idx = cm.final_index(SEED, np.zeros(N))
+        assert csmc.engine.last_final_index() == idx
+        _eq(traj, x0[idx].reshape(traj.shape), "T=1 trajectory")
+        return
+    trajo, Xo, ANCo, lwo = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
+    X, ANC, LW, _ = csmc.engine.traces()
+    _eq(X, Xo, "state_trace")
+    _eq(ANC[: pb.T - 1], ANCo, "ancestor_trace")
+    _eq(traj, trajo.reshape(traj.shape), "trajectory")
