@@ -161,11 +161,23 @@ __device__ __forceinline__ uint64_t wave_incl_scan_u64(uint64_t v) {
     v += dpp_u64<PG_DPP_ROW_BCAST31, 0xc>(v);
     return v;
 }
-// maximum over the wave (NaN ignored, any sign): butterfly in the row, then across rows through lane reads
+// maximum over the wave (NaN ignored, any sign).  Lanes without a DPP source keep their own value (`old` = own), so
+// negative values and -inf are handled; the result is read from lane 63 (scalar broadcast).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_keep_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = __builtin_fmax(v, __shfl_xor(v, off));
-    return v;
+    v = __builtin_fmax(v, dpp_keep_f64<PG_DPP_ROW_SHR(1), 0xf>(v));
+    v = __builtin_fmax(v, dpp_keep_f64<PG_DPP_ROW_SHR(2), 0xf>(v));
+    v = __builtin_fmax(v, dpp_keep_f64<PG_DPP_ROW_SHR(4), 0xf>(v));
+    v = __builtin_fmax(v, dpp_keep_f64<PG_DPP_ROW_SHR(8), 0xf>(v));
+    v = __builtin_fmax(v, dpp_keep_f64<PG_DPP_ROW_BCAST15, 0xa>(v));
+    v = __builtin_fmax(v, dpp_keep_f64<PG_DPP_ROW_BCAST31, 0xc>(v));
+    return readlane_f64(v, 63);
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, PG_DPP_ROW_SHR(1), 0xf, 0xf, true);

@@ -1,0 +1,19 @@
+"""Sweep time of the other BASELINE configurations at N = 2^20 (shortened T), for DESIGN.md (development aid)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import pgas_amd
+from pgas_amd import experiments
+N = 1 << 20
+for name, pb in (("SMO M=41 (2-D)", experiments.smo_pgas(T=200)), ("EMPS M=729 (3-D)", experiments.emps_pgas(T=100)), ("Toy M=40 (1-D, nx=1)", experiments.toy(T=40))):
+    A, S = experiments.initial_params(pb)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+    csmc(1, pb.X_true, A, S); torch.cuda.synchronize()
+    csmc.engine.set_profiling(True)
+    t0 = time.perf_counter(); csmc(2, pb.X_true, A, S); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    n, ms, pn, pm = csmc.engine.profile()
+    print(f"{name:24s} T={pb.T:4d}: {1e3*dt:8.2f} ms/sweep = {1e6*dt/(pb.T-1):7.2f} us/step, {N*(pb.T-1)/dt:.3e} particle-steps/s; "
+          f"k_resample {1e3*ms/max(n,1):6.2f} us/launch, k_propagate {1e3*pm/max(pn,1):7.2f} us/launch")
+    csmc.engine.close()
+    del csmc
+    torch.cuda.empty_cache()
