@@ -419,7 +419,9 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
         // pipeline A (caller's stream): every particle through all time steps; independent of the weights (quirk Q1).
         // pipeline B (internal stream when overlap is on): the weight recursion, gated chunk by chunk on
         // pipeline A by events, so that its latency-bound launches run underneath k_propagate's arithmetic.
-        const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 1 : T);
+        // default chunk, measured (tools/overlap_exp.sh, tools/config_times.py): one step per launch for the cheap 1-D / 2-D bases,
+        // 16 for the 3-D bases whose k_propagate launches are ten times longer than a k_resample launch
+        const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? (md.D >= 3 ? 16 : 1) : T);
         const int nchunk = (T - 1 + chunk - 1) / chunk;
         hipStream_t sb_stream = st;
         if (c->overlap) {

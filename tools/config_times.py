@@ -5,9 +5,15 @@ import numpy as np, torch
 import pgas_amd
 from pgas_amd import experiments
 N = 1 << 20
-for name, pb in (("SMO M=41 (2-D)", experiments.smo_pgas(T=200)), ("EMPS M=729 (3-D)", experiments.emps_pgas(T=100)), ("Toy M=40 (1-D, nx=1)", experiments.toy(T=40))):
+cfgs = (("SMO M=41 (2-D)", lambda: experiments.smo_pgas(T=200)), ("EMPS M=729 (3-D)", lambda: experiments.emps_pgas(T=100)), ("Toy M=40 (1-D, nx=1)", lambda: experiments.toy(T=40)))
+for name, mk in [c for c in cfgs if os.environ.get("ONLY", "") in c[0]]:
+    pb = mk()
     A, S = experiments.initial_params(pb)
     csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+    if os.environ.get("NO_OVERLAP"):
+        csmc.engine.set_option(3, 0)
+    if os.environ.get("CHUNK"):
+        csmc.engine.set_option(1, int(os.environ["CHUNK"]))
     csmc(1, pb.X_true, A, S); torch.cuda.synchronize()
     csmc.engine.set_profiling(True)
     t0 = time.perf_counter(); csmc(2, pb.X_true, A, S); torch.cuda.synchronize(); dt = time.perf_counter() - t0
