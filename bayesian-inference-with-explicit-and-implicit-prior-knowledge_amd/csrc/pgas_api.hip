@@ -109,6 +109,7 @@ struct pgas_ctx {
     double* d_phi = nullptr;
     // optional per-launch timing of the dominant kernel (pgas_set_profiling)
     int profiling = 0;
+    int prof_stride = 16;       // bracket every prof_stride-th launch with events (an event pair costs ~3 us of stream time)
     std::vector<hipEvent_t> ev;      // pairs (start, stop) around each k_resample launch of the last sweep
     std::vector<hipEvent_t> evp;     // pairs (start, stop) around each k_propagate launch of the last sweep
     int evp_used = 0;
@@ -446,7 +447,8 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
         // launches are issued chunk by chunk, pipeline A first, so both device queues stay fed
         for (int ci = 0; ci < nchunk; ++ci) {
             const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
-            if (c->profiling) {
+            const bool ptimed = c->profiling && (ci % c->prof_stride) == 0;
+            if (ptimed) {
                 while ((int)c->evp.size() < c->evp_used + 2) {
                     hipEvent_t e;
                     HIPCHK(c, hipEventCreate(&e));
@@ -456,7 +458,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
             }
             hipLaunchKernelGGL(c->var.prop, grid, blk, c->overlap ? c->prop_lds : 0, st, md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
             KCHK(c, "k_propagate");
-            if (c->profiling) { HIPCHK(c, hipEventRecord(c->evp[c->evp_used + 1], st)); c->evp_used += 2; }
+            if (ptimed) { HIPCHK(c, hipEventRecord(c->evp[c->evp_used + 1], st)); c->evp_used += 2; }
             if (c->overlap) {
                 HIPCHK(c, hipEventRecord(c->ev_chunk[ci], st));
                 HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_chunk[ci], 0));
@@ -474,7 +476,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
                 const double* h_t = t < T ? c->h_buf + (size_t)t * np : (const double*)nullptr;
                 int32_t* anc = t > 1 ? c->anc_trace + (size_t)(t - 2) * N : (int32_t*)nullptr;
                 double* lwo = t == T ? c->logw_last : ((c->logw_trace && t > 1) ? c->logw_trace + (size_t)(t - 1) * N : (double*)nullptr);
-                const bool timed = c->profiling && t < T;
+                const bool timed = c->profiling && t < T && (t % c->prof_stride) == 0;
                 if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], sb_stream));
                 if (fast) {
                     hipLaunchKernelGGL(k_resample_fast, dim3(md.nseg + 1), blk, 0, sb_stream, md, t, mode, ++c->launch_tag, u1p, u2p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
@@ -534,6 +536,7 @@ int pgas_last_final_index(pgas_ctx* c, int64_t* idx, void* stream) {
 int pgas_set_profiling(pgas_ctx* c, int32_t on) {
     if (!c) return PGAS_E_ARG;
     c->profiling = on ? 1 : 0;
+    if (on > 1) c->prof_stride = on;  // on = n > 1: sample every n-th launch
     return PGAS_OK;
 }
 

@@ -169,7 +169,7 @@ def main():
             us = 1e3 * prof_ms / prof_n
             achieved = ALG_BYTES_PER_PARTICLE_STEP * N / (us * 1e-6) / 1e9
             p_us = 1e3 * prop_ms / max(prop_n, 1)
-            p_steps = (T - 1) * args.steps / max(prop_n, 1)
+            p_steps = args.chunk if args.chunk > 0 else 1   # time steps per k_propagate launch (engine default for this 2-D basis: 1)
             traffic, p_traffic = None, None
             tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
             if os.path.exists(tf):
@@ -177,9 +177,10 @@ def main():
                 traffic, p_traffic = tj.get("k_resample_fast_hbm_bytes_per_launch"), tj.get("k_propagate_hbm_bytes_per_step")
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "k_resample_fast", "avg_launch_us": us, "launches": prof_n,
+                "traffic": traffic, "kernel": "k_resample_fast", "avg_launch_us": us, "launches_timed": prof_n,
+                "launch_sampling": "every 16th launch is bracketed with HIP events (an event pair costs ~3 us of stream time)",
                 "alg_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * N,
-                "second_kernel": {"kernel": "k_propagate<2,2,8,2,2>", "avg_launch_us": p_us, "launches": prop_n, "steps_per_launch": p_steps,
+                "second_kernel": {"kernel": "k_propagate<2,2,8,2,2>", "avg_launch_us": p_us, "launches_timed": prop_n, "steps_per_launch": p_steps,
                                   "achieved_GBs": ALG_BYTES_PER_PARTICLE_STEP * N * p_steps / (p_us * 1e-6) / 1e9,
                                   "traffic_per_step": p_traffic},
                 "note": "the two kernels run concurrently on two streams; both are fp64-VALU-bound (DESIGN.md section 5), "
