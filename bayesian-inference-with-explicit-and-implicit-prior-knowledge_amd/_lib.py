@@ -251,7 +251,8 @@ class Engine:
         return int(v.value)
 
     def set_profiling(self, on):
-        self._chk(self.lib.pgas_set_profiling(self._h, 1 if on else 0), "pgas_set_profiling")
+        """False/0 = off, True/1 = on at the default sampling stride, n > 1 = time every n-th launch."""
+        self._chk(self.lib.pgas_set_profiling(self._h, int(on)), "pgas_set_profiling")
 
     def profile(self):
         """(k_resample launches, their total ms, k_propagate launches, their total ms) of the last sweep (synchronises)."""

@@ -1,6 +1,7 @@
 // pgas_api.hip -- C ABI of libpgas_hip.so (include/pgas_hip.h) over the kernels of
 // pgas_kernels.hip.h.  Host side only: argument checking, device tables, launch sequencing.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdio>
@@ -109,7 +110,7 @@ struct pgas_ctx {
     double* d_phi = nullptr;
     // optional per-launch timing of the dominant kernel (pgas_set_profiling)
     int profiling = 0;
-    int prof_stride = 16;       // bracket every prof_stride-th launch with events (an event pair costs ~3 us of stream time)
+    int prof_stride = 16;       // every prof_stride-th launch carries start/stop events (hipExtLaunchKernelGGL: the dispatch's own timestamps)
     std::vector<hipEvent_t> ev;      // pairs (start, stop) around each k_resample launch of the last sweep
     std::vector<hipEvent_t> evp;     // pairs (start, stop) around each k_propagate launch of the last sweep
     int evp_used = 0;
@@ -454,11 +455,14 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
                     HIPCHK(c, hipEventCreate(&e));
                     c->evp.push_back(e);
                 }
-                HIPCHK(c, hipEventRecord(c->evp[c->evp_used], st));
+                // start/stop events bound to the dispatch itself: they carry the kernel's own begin/end timestamps
+                hipExtLaunchKernelGGL(c->var.prop, grid, blk, c->overlap ? c->prop_lds : 0, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, md, c->tp, seed,
+                                      t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
+                c->evp_used += 2;
+            } else {
+                hipLaunchKernelGGL(c->var.prop, grid, blk, c->overlap ? c->prop_lds : 0, st, md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
             }
-            hipLaunchKernelGGL(c->var.prop, grid, blk, c->overlap ? c->prop_lds : 0, st, md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
             KCHK(c, "k_propagate");
-            if (ptimed) { HIPCHK(c, hipEventRecord(c->evp[c->evp_used + 1], st)); c->evp_used += 2; }
             if (c->overlap) {
                 HIPCHK(c, hipEventRecord(c->ev_chunk[ci], st));
                 HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_chunk[ci], 0));
@@ -477,16 +481,17 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
                 int32_t* anc = t > 1 ? c->anc_trace + (size_t)(t - 2) * N : (int32_t*)nullptr;
                 double* lwo = t == T ? c->logw_last : ((c->logw_trace && t > 1) ? c->logw_trace + (size_t)(t - 1) * N : (double*)nullptr);
                 const bool timed = c->profiling && t < T && (t % c->prof_stride) == 0;
-                if (timed) HIPCHK(c, hipEventRecord(c->ev[c->ev_used], sb_stream));
+                hipEvent_t e0 = timed ? c->ev[c->ev_used] : (hipEvent_t) nullptr, e1 = timed ? c->ev[c->ev_used + 1] : (hipEvent_t) nullptr;
+                if (timed) c->ev_used += 2;
                 if (fast) {
-                    hipLaunchKernelGGL(k_resample_fast, dim3(md.nseg + 1), blk, 0, sb_stream, md, t, mode, ++c->launch_tag, u1p, u2p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
+                    hipExtLaunchKernelGGL(k_resample_fast, dim3(md.nseg + 1), blk, 0, sb_stream, e0, e1, 0, md, t, mode, ++c->launch_tag, u1p, u2p, la_t, h_t,
+                                          c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
                     KCHK(c, "k_resample_fast");
                 } else {
-                    hipLaunchKernelGGL(k_resample, grid, blk, 0, sb_stream, md, t, mode, u1p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, c->peers,
-                                       (int64_t)((size_t)(t - 1) * np), anc, lwo);
+                    hipExtLaunchKernelGGL(k_resample, grid, blk, 0, sb_stream, e0, e1, 0, md, t, mode, u1p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn,
+                                          c->peers, (int64_t)((size_t)(t - 1) * np), anc, lwo);
                     KCHK(c, "k_resample");
                 }
-                if (timed) { HIPCHK(c, hipEventRecord(c->ev[c->ev_used + 1], sb_stream)); c->ev_used += 2; }
                 if (!fast && t < T) {
                     rc = launch_upper(c, sn, 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, sb_stream);
                     if (rc) return rc;
@@ -536,7 +541,8 @@ int pgas_last_final_index(pgas_ctx* c, int64_t* idx, void* stream) {
 int pgas_set_profiling(pgas_ctx* c, int32_t on) {
     if (!c) return PGAS_E_ARG;
     c->profiling = on ? 1 : 0;
-    if (on > 1) c->prof_stride = on;  // on = n > 1: sample every n-th launch
+    if (on > 1) c->prof_stride = on;  // on = n > 1: time every n-th launch
+    if (on < 0) c->prof_stride = 1;   // on < 0: time every launch
     return PGAS_OK;
 }
 

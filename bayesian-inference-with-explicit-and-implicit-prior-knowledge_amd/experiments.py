@@ -10,6 +10,11 @@ differs from JAX's).  Nothing here is on the timed path.
 * Toy       : src/Toy_Example.py, the only data-free PGAS instantiation in the reference.
 * EMPS-PGAS (config 5): src/EMPS.py:101-123,243-255 with synthetic data from the reference's
   linear-friction model (:169-193) because DATA_EMPS.mat is not distributed.
+* Vehicle-PGAS (config 3): src/Vehicle.py data (constants, Pacejka tyre curve, RK4, steering
+  profile) with a plain-PGAS instantiation over a 3-D Hilbert basis of (yaw rate, lateral velocity,
+  steering angle), M = 729 -- the "larger basis-function set".  The reference only runs Vehicle
+  through Algorithm1/2 (marginalised); this PGAS instantiation, its observation
+  model y = x + e and its basis scaling are the BUILD's interpretation of BASELINE.json configs[2].
 """
 from __future__ import annotations
 
@@ -117,6 +122,47 @@ def emps_pgas(T=2000, seed=12345678, M=729):
     prior = prior_mniw_2naturalPara(np.zeros((2, M)), np.diag(sd), np.eye(2), 2)                       # :116-123
     bmap = basis.on([0, 1, 2], div=[0.4, 0.4, 160])        # :110-113
     return Problem("EMPS-PGAS", Y, tau, x0, P0, GaussianLikelihood.of_component(0, 2, R), bmap, prior, X)
+
+
+# ---------------------------------------------------------------- Vehicle lateral dynamics (synthetic data)
+def vehicle_pgas(T=2000, seed=12345678, M=729):
+    m, I_zz, l_f, l_r, g, mu_x = 1720.0, 1827.5, 1.16, 1.47, 9.81, 0.9   # src/Vehicle.py:17-22
+    mu, B, C, E = 0.9, 10.0, 1.9, 0.97                                    # :23-26
+    dt = 0.02                                                             # :183
+    t_end = T * dt
+    time = np.arange(T) * dt
+    F_zf, F_zr = m * g * l_r / (l_f + l_r), m * g * l_f / (l_f + l_r)     # :30-36
+
+    def mu_y(alpha):                                                      # :40-47
+        return mu * np.sin(C * np.arctan(B * (1 - E) * np.tan(alpha) + E * np.arctan(B * np.tan(alpha))))
+
+    def f_alpha(x, u):                                                    # :51-58
+        return u[0] - np.arctan((x[1] + x[0] * l_f) / u[1]), -np.arctan((x[1] - x[0] * l_r) / u[1])
+
+    def dx(x, u, mf, mr):                                                 # :62-86
+        dv_y = (F_zf * mf * np.cos(u[0]) + F_zr * mr + F_zf * mu_x * np.sin(u[0])) / m - u[1] * x[0]
+        ddpsi = (l_f * F_zf * mf * np.cos(u[0]) - l_r * F_zr * mr + l_f * F_zf * mu_x * np.sin(u[0])) / I_zz
+        return np.array([ddpsi, dv_y])
+
+    ctrl = np.zeros((T, 2))                                               # :199-208
+    ctrl[:, 0] = 10 / 180 * np.pi * np.sin(2 * np.pi * time / 5) * np.exp(-0.5 * (time - t_end / 2) ** 2 / (t_end / 5) ** 2)
+    ctrl[:, 1] = 11.0
+    x0, P0 = np.array([0.0, 0.0]), np.diag([1e-4, 1e-4])                  # :190-191
+    R, Q = np.diag([0.001 / 180 * np.pi, 1e-3]), np.diag([1e-8, 1e-8])    # :195-196
+    rng = np.random.default_rng(seed)
+    X, Y = np.zeros((T, 2)), np.zeros((T, 2))
+    X[0] = x0
+    for i in range(1, T):                                                 # :226-257 (tyre forces frozen over the step, RK4 :90-100)
+        s, u = X[i - 1], ctrl[i - 1]
+        af, ar = f_alpha(s, u)
+        mf, mr = mu_y(af), mu_y(ar)
+        k1 = dx(s, u, mf, mr); k2 = dx(s + dt * k1 / 2, u, mf, mr); k3 = dx(s + dt * k2 / 2, u, mf, mr); k4 = dx(s + dt * k3, u, mf, mr)
+        X[i] = s + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4) + np.sqrt(np.diag(Q)) * rng.standard_normal(2)
+        Y[i] = X[i] + np.sqrt(np.diag(R)) * rng.standard_normal(2)       # build's observation model: both states, reference R
+    basis, sd = generate_Hilbert_BasisFunction(M, np.array([[-1, 1], [-1, 1], [-1, 1]]), 0.5 / M, 20)  # as EMPS-729 (src/EMPS.py:101-107)
+    prior = prior_mniw_2naturalPara(np.zeros((2, M)), np.diag(sd), np.eye(2), 2)
+    bmap = basis.on([0, 1, 2], div=[1.0, 2.0, 0.25])      # |yaw rate| < 1 rad/s, |v_y| < 2 m/s, |steer| < 0.25 rad
+    return Problem("Vehicle-PGAS", Y, ctrl, x0, P0, GaussianLikelihood(np.eye(2), R), bmap, prior, X)
 
 
 def initial_params(problem: Problem):

@@ -50,6 +50,21 @@ def cpu_baseline(pb, A, S, N, seed, steps):
     }
 
 
+def hbm_copy_rate(torch, device, nbytes=1 << 30, reps=10):
+    """Attainable HBM rate of a plain device copy (read + write of `nbytes`), the yardstick SURVEY 8(d) asks for next to the 8 TB/s spec."""
+    src = torch.empty(nbytes // 8, dtype=torch.float64, device=device).normal_()
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +77,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=-1, help="time steps per k_propagate launch (engine default if < 0)")
     ap.add_argument("--no-overlap", action="store_true", help="run the weight recursion on the caller's stream (no concurrency)")
     ap.add_argument("--prop-lds", type=int, default=-1, help="LDS bytes reserved per k_propagate workgroup while overlapping (engine default if < 0)")
+    ap.add_argument("--workload", choices=["smo", "vehicle", "emps"], default="smo",
+                    help="smo = BASELINE configs[1] (the metric's configuration, default); vehicle = configs[2]; emps = configs[4]'s per-GPU chain")
     ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
                     help="multi-GPU partition: independent chains, one per GPU (default; BASELINE config 5) or ONE sweep whose "
                          "--particles x G particles are sharded over the G ranks (RCCL all-gather per step + xGMI peer reads; config 4)")
@@ -88,14 +105,18 @@ def main():
     N, T = args.particles, args.T
     sharded_mode = args.mode == "sharded" and world > 1
     seed = 12345678 + (0 if sharded_mode else rank)  # independent chains differ by seed (BASELINE config 5 convention: 12345678 + g)
-    pb = experiments.smo_pgas(T=T)
+    pb = {"smo": experiments.smo_pgas, "vehicle": experiments.vehicle_pgas, "emps": experiments.emps_pgas}[args.workload](T=T)
+    wl_name = {"smo": "SingleMassOscillator PGAS sweep, nx=2, M=41 Hilbert basis (BASELINE.json configs[1])",
+               "vehicle": "Vehicle lateral dynamics PGAS sweep, nx=2, ny=2, M=729 3-D Hilbert basis (BASELINE.json configs[2], build's instantiation)",
+               "emps": "EMPS PGAS sweep on synthetic data, nx=2, M=729 3-D Hilbert basis (one chain of BASELINE.json configs[4])"}[args.workload]
     pg = pgas_amd.PGAS(N, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior,
                        pb.basis_fcn, device=f"cuda:{local_rank}")
     eng = pg.cSMC.engine
     ref = torch.as_tensor(pb.X_true, device=eng.device)
     # (A, S) from one sample_params on the initial reference trajectory
     A, S = pg.sample_params(pgas_amd.random.key(seed), ref)
-    eng.set_profiling(not args.no_profile)
+    stride = int(os.environ.get("PGAS_PROF_STRIDE", "1"))       # time every stride-th launch of the profiled sweep(s)
+    prof_all = os.environ.get("PGAS_PROF_ALL", "0") == "1"      # profile every timed sweep instead of the last one only
     if args.chunk >= 0:
         eng.set_option(1, args.chunk)      # PGAS_OPT_PROPAGATE_CHUNK
     if args.no_overlap:
@@ -131,9 +152,14 @@ def main():
     t0 = time.perf_counter()
     prof_n, prof_ms, prop_n, prop_ms = 0, 0.0, 0, 0.0
     for k in range(args.steps):
+        # kernel durations: the LAST timed sweep launches every k_resample_fast / k_propagate with start/stop HIP events
+        # (hipExtLaunchKernelGGL: the dispatch's own begin/end timestamps, on the streams the kernels run on).  Timing every
+        # launch of every sweep would cost ~8 % of the headline value; one sweep of K gives 2 x (T-1) samples inside the timed region.
+        timed_sweep = not args.no_profile and (k == args.steps - 1 or prof_all)
+        eng.set_profiling((-1 if stride == 1 else stride) if timed_sweep else 0)
         one_sweep(seed + k)
-        if not args.no_profile:
-            n, ms, pn, pm = eng.profile()   # synchronises this sweep; the events sit inside the timed region
+        if timed_sweep:
+            n, ms, pn, pm = eng.profile()   # synchronises this sweep
             prof_n += n
             prof_ms += ms
             prop_n += pn
@@ -147,13 +173,12 @@ def main():
 
     units = N * (T - 1) * args.steps * world
     out = {
-        "metric": "particle-steps/sec (N x (T-1) / wall), SingleMassOscillator PGAS conditional-SMC sweep",
+        "metric": "particle-steps/sec (N x (T-1) / wall), " + {"smo": "SingleMassOscillator", "vehicle": "Vehicle", "emps": "EMPS"}[args.workload] + " PGAS conditional-SMC sweep",
         "value": units / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"SingleMassOscillator PGAS sweep, N={N} particles/GPU, T={T}, nx=2, M=41 Hilbert basis, fp64 "
-                        f"(BASELINE.json configs[1])",
+            "workload": f"{wl_name}, N={N} particles/GPU, T={T}, fp64",
             "particles_per_gpu": N, "T": T,
             "parallelism": "1 GPU" if world == 1 else (
                 f"one sweep of {N * world} particles sharded over {world} GPUs: RCCL all-gather of segment partials per step + xGMI peer reads"
@@ -169,7 +194,7 @@ def main():
             us = 1e3 * prof_ms / prof_n
             achieved = ALG_BYTES_PER_PARTICLE_STEP * N / (us * 1e-6) / 1e9
             p_us = 1e3 * prop_ms / max(prop_n, 1)
-            p_steps = args.chunk if args.chunk > 0 else 1   # time steps per k_propagate launch (engine default for this 2-D basis: 1)
+            p_steps = args.chunk if args.chunk > 0 else (1 if args.workload == "smo" else 16)   # time steps per k_propagate launch (engine default: 1 for 2-D bases, 16 for 3-D)
             traffic, p_traffic = None, None
             tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
             if os.path.exists(tf):
@@ -178,9 +203,11 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "kernel": "k_resample_fast", "avg_launch_us": us, "launches_timed": prof_n,
-                "launch_sampling": "every 16th launch is bracketed with HIP events (an event pair costs ~3 us of stream time)",
+                "launch_sampling": f"every {'launch' if stride == 1 else str(stride) + 'th launch'} of {'every timed sweep' if prof_all else 'the last timed sweep'} "
+                                   "carries start/stop HIP events (hipExtLaunchKernelGGL)",
                 "alg_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * N,
-                "second_kernel": {"kernel": "k_propagate<2,2,8,2,2>", "avg_launch_us": p_us, "launches_timed": prop_n, "steps_per_launch": p_steps,
+                "hbm_copy_GBs": hbm_copy_rate(torch, eng.device),   # measured attainable rate of a 1 GiB device copy, outside the timed region
+                "second_kernel": {"kernel": "k_propagate<2,2,8,2,2>" if args.workload == "smo" else "k_propagate<2,3,12,2,2>", "avg_launch_us": p_us, "launches_timed": prop_n, "steps_per_launch": p_steps,
                                   "achieved_GBs": ALG_BYTES_PER_PARTICLE_STEP * N * p_steps / (p_us * 1e-6) / 1e9,
                                   "traffic_per_step": p_traffic},
                 "note": "the two kernels run concurrently on two streams; both are fp64-VALU-bound (DESIGN.md section 5), "

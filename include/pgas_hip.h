@@ -117,12 +117,12 @@ int pgas_get_traces(pgas_ctx* ctx, double** x_trace, int32_t** anc_trace, double
 /* Index drawn by the last sweep at src/PGAS.py:225 (synchronises the stream). */
 int pgas_last_final_index(pgas_ctx* ctx, int64_t* idx, void* stream);
 
-/* Measurement aid (bench.py): when on, pgas_sweep brackets its kernels with HIP events on the caller's
- * stream(s): every per-step k_resample(_fast) launch (resampling search + softmax scans) and every k_propagate
- * launch (all particles through a chunk of time steps).  pgas_get_profile synchronises and returns, for the last
- * sweep, the counts and summed durations of the launches that were bracketed: every 16th by default (on = 1), every
- * n-th for on = n > 1 -- an event pair costs about 3 us of stream time, so bracketing every launch would slow the sweep
- * it measures by ~12 %.
+/* Measurement aid (bench.py): when on, pgas_sweep launches its two per-step kernels -- k_resample(_fast) (resampling
+ * search + softmax scans) and k_propagate (all particles through a chunk of time steps) -- with start/stop HIP events
+ * attached to the dispatch (hipExtLaunchKernelGGL), which carry the kernel's own begin/end timestamps on the stream it
+ * runs on.  pgas_get_profile synchronises and returns, for the last sweep, the counts and summed durations of the launches
+ * that were timed: every 16th by default (on = 1), every n-th for on = n > 1, every launch for on < 0 (timing every launch
+ * slows the sweep it measures by ~8 %: timed dispatches serialise with their neighbours on the stream).
  * No reference counterpart (the reference has no timing code). */
 int pgas_set_profiling(pgas_ctx* ctx, int32_t on);
 int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample_ms, int64_t* propagate_launches,

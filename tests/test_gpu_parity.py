@@ -22,6 +22,8 @@ def _problems():
         "toy": lambda: experiments.toy(T=40),
         "emps": lambda: experiments.emps_pgas(T=10),
         "emps27": lambda: experiments.emps_pgas(T=16, M=27),
+        "veh": lambda: experiments.vehicle_pgas(T=12),           # ny = 2, nu = 2, M = 729 (BASELINE configs[2])
+        "veh27": lambda: experiments.vehicle_pgas(T=300, M=27),
     }
 
 
@@ -48,7 +50,7 @@ def test_library_loaded_is_in_tree():
     assert "libpgas_hip.so" in maps, "native library not mapped into the test process"
 
 
-@pytest.mark.parametrize("name,N", [("smo", 200), ("smo", 1024), ("smo", 1025), ("smo", 70000), ("toy", 777), ("emps", 1500), ("emps27", 3000)])
+@pytest.mark.parametrize("name,N", [("smo", 200), ("smo", 1024), ("smo", 1025), ("smo", 70000), ("toy", 777), ("emps", 1500), ("emps27", 3000), ("veh", 1300), ("veh27", 2500)])
 def test_basis_init_step_bit_exact(name, N):
     pb, A, S, cm, csmc = _setup(name, N)
     eng = csmc.engine
@@ -76,7 +78,7 @@ def test_basis_init_step_bit_exact(name, N):
 
 
 @pytest.mark.parametrize("name,N,opts", [
-    ("smo", 200, {}), ("smo", 4096, {}), ("smo", 5000, {}), ("toy", 1500, {}), ("emps", 2048, {}), ("smo", 1 << 17, {}),
+    ("smo", 200, {}), ("smo", 4096, {}), ("smo", 5000, {}), ("toy", 1500, {}), ("emps", 2048, {}), ("veh", 2048, {}), ("veh27", 3000, {}), ("smo", 1 << 17, {}),
     ("smo", 5000, {2: 1}),            # PGAS_OPT_FORCE_SLOW_RESAMPLE: the k_resample + k_upper pair used when N > 2^20 per device
     ("smo", 70000, {2: 1, 1: 7}),     # ... with k_propagate launched in chunks of 7 time steps
     ("toy", 1500, {1: 1}),            # PGAS_OPT_PROPAGATE_CHUNK = 1: one k_propagate launch per step
@@ -181,7 +183,7 @@ def test_error_reporting():
                                           lambda o, s, i: 0.0, pb.basis_fcn)
 
 
-@pytest.mark.parametrize("name,N,world", [("smo", 4096, 2), ("smo", 8192, 4), ("smo", 65536, 8), ("toy", 2048, 2), ("emps", 2048, 2)])
+@pytest.mark.parametrize("name,N,world", [("smo", 4096, 2), ("smo", 8192, 4), ("smo", 65536, 8), ("toy", 2048, 2), ("emps", 2048, 2), ("veh27", 4096, 2)])
 def test_sharded_sweep_bit_exact_and_independent_of_world(name, N, world):
     """Particle-sharded sweep (several shards emulated in one process on one device): the trajectory and the traces are the
     single-device / oracle ones bit for bit, whatever the number of shards."""

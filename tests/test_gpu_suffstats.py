@@ -16,7 +16,8 @@ def _phi_numpy(pb):
     return np.vstack([nm.basis(pb.X_true[t : t + 1], u[t]) for t in range(T - 1)])  # traj[:-1] with inputs[:-1] (Q3)
 
 
-@pytest.mark.parametrize("maker", [lambda: experiments.smo_pgas(T=300), lambda: experiments.toy(T=40), lambda: experiments.emps_pgas(T=50)])
+@pytest.mark.parametrize("maker", [lambda: experiments.smo_pgas(T=300), lambda: experiments.toy(T=40), lambda: experiments.emps_pgas(T=50),
+                                   lambda: experiments.vehicle_pgas(T=60, M=27)])
 def test_suffstats_match_numpy(maker):
     pb = maker()
     pg = pgas_amd.PGAS(256, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior, pb.basis_fcn)

@@ -74,3 +74,6 @@ def test_experiment_definitions():
     assert e.basis_fcn.basis.M == 729 and np.abs(e.X_true[:, 0]).max() < 0.4 and np.abs(e.inputs).max() < 160
     t = experiments.toy()
     assert t.inputs.shape == (40, 0) and t.basis_fcn.basis.M == 40
+    v = experiments.vehicle_pgas(T=300)
+    assert v.basis_fcn.basis.M == 729 and v.observations.shape == (300, 2) and v.inputs.shape == (300, 2)
+    assert np.all(v.inputs[:, 1] == 11.0) and np.abs(v.inputs[:, 0]).max() < 0.25

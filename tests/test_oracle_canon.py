@@ -17,10 +17,11 @@ SEED = 12345678
 
 def _mk(name):
     return {"smo": lambda: experiments.smo_pgas(T=30), "toy": lambda: experiments.toy(T=40),
-            "emps27": lambda: experiments.emps_pgas(T=10, M=27), "emps": lambda: experiments.emps_pgas(T=5)}[name]()
+            "emps27": lambda: experiments.emps_pgas(T=10, M=27), "emps": lambda: experiments.emps_pgas(T=5),
+            "veh27": lambda: experiments.vehicle_pgas(T=400, M=27)}[name]()
 
 
-@pytest.mark.parametrize("name,N", [("smo", 200), ("smo", 3000), ("toy", 500), ("emps27", 1500), ("emps", 200)])
+@pytest.mark.parametrize("name,N", [("smo", 200), ("smo", 3000), ("toy", 500), ("emps27", 1500), ("emps", 200), ("veh27", 700)])
 def test_teacher_forced_steps_match_numpy(name, N):
     pb = _mk(name)
     A, S = experiments.initial_params(pb)
