@@ -26,7 +26,10 @@ from .descriptors import BasisMap, GaussianLikelihood
 
 class condSequentialMonteCarlo:
     def __init__(self, N_samples, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn,
-                 device=None, keep_logw_trace=False):
+                 device=None, keep_logw_trace=False, resample_before_propagate=False):
+        """resample_before_propagate=True selects the CORRECTED mode: x_t[i] is drawn from the transition of the resampled
+        ancestor x_{t-1}[a_i].  The reference (and the default here) propagates x_{t-1}[i] itself (src/PGAS.py:131-133,
+        SURVEY quirk Q1) although it records and weights with a_i; the corrected mode is NOT the reference's behaviour."""
         if not isinstance(likelihood_fcn, GaussianLikelihood):
             raise TypeError("likelihood_fcn must be a pgas_amd.GaussianLikelihood descriptor (HIP kernels cannot trace Python callables)")
         if not isinstance(basis_fcn, BasisMap):
@@ -43,6 +46,9 @@ class condSequentialMonteCarlo:
         self.engine = Engine(self.N_samples, self.observations, self.inputs, self.init_state_mean, self.init_state_cov,
                              likelihood_fcn, basis_fcn, device=device, keep_logw_trace=keep_logw_trace)
         self.device = self.engine.device
+        self.resample_before_propagate = bool(resample_before_propagate)
+        if self.resample_before_propagate:
+            self.engine.set_option(5, 1)  # PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE
 
     # src/PGAS.py:45-57
     def _generate_auxiliary_states(self, state, time, coeff_mat, error_cov=None):
@@ -66,11 +72,12 @@ class condSequentialMonteCarlo:
 
 class PGAS:
     def __init__(self, N_samples, N_iterations, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn,
-                 GP_prior, basis_fcn, device=None):
+                 GP_prior, basis_fcn, device=None, resample_before_propagate=False):
         self.N_iterations = int(N_iterations)
         self.N_steps = np.asarray(observations).shape[0]
         self.cSMC = condSequentialMonteCarlo(N_samples, observations, inputs, init_state_mean, init_state_cov,
-                                             likelihood_fcn, basis_fcn, device=device)
+                                             likelihood_fcn, basis_fcn, device=device,
+                                             resample_before_propagate=resample_before_propagate)
         dev = self.cSMC.device
         f = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)  # noqa: E731
         self.GP_prior = (f(GP_prior[0]), f(GP_prior[1]), f(np.atleast_2d(GP_prior[2])), float(GP_prior[3]))

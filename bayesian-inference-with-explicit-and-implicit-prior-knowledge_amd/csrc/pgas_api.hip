@@ -21,7 +21,8 @@ namespace {
 
 thread_local std::string g_create_error;
 
-typedef void (*front_fn)(DevModel, TransParams, int, uint64_t, const double*, const double*, const double*, double*, ScanBufs);
+typedef void (*front_fn)(DevModel, TransParams, int, uint64_t, const double*, const double*, const double*, int, double*, ScanBufs);
+typedef void (*backc_fn)(DevModel, TransParams, int, uint64_t, double, const double*, const double*, ScanBufs, int32_t*, double*, double*);
 typedef void (*prop_fn)(DevModel, TransParams, uint64_t, int, int, double*, const double*, double*, double*, double*);
 typedef void (*aux_fn)(DevModel, TransParams, int, const double*, double*);
 typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, int32_t*, double*);
@@ -67,6 +68,9 @@ struct pgas_ctx {
     int keep_logw = 0;
     Variant var{};
     back_fn back = nullptr;
+    backc_fn back_corrected = nullptr;
+    int corrected = 0;          // PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE: propagate from the resampled ancestors (quirk Q1 removed)
+    double* aux_buf = nullptr;  // (N, nx) transition means of the current step, corrected mode only
     init_fn init = nullptr;
     basis_fn basis = nullptr;
     // device tables
@@ -216,6 +220,7 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
     if (!pick_variant(d->nx, d->D, md.J[d->D - 1], &c->var, &md.JP))
         FAIL(c, PGAS_E_ARG, "pgas_create: innermost basis dimension has %d frequencies (compiled up to 16)", md.J[d->D - 1]);
     c->back = d->nx == 1 ? k_back<1> : k_back<2>;
+    c->back_corrected = d->nx == 1 ? k_back_corrected<1> : k_back_corrected<2>;
     c->init = d->nx == 1 ? k_init<1> : k_init<2>;
     c->basis = d->nx == 1 ? k_basis_eval<1> : k_basis_eval<2>;
     c->keep_logw = d->keep_logw_trace;
@@ -278,7 +283,7 @@ void pgas_destroy(pgas_ctx* c) {
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
     hipFree(c->segm_g[0]); hipFree(c->segm_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
-    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf);
+    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (hipEvent_t e : c->evp) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
@@ -361,12 +366,19 @@ int pgas_step(pgas_ctx* c, int32_t t, uint64_t seed, const double* logw_dev, con
     hipStream_t st = (hipStream_t)stream;
     const DevModel& md = c->md;
     HIPCHK(c, hipMemcpyAsync(c->d_ref, ref_t_host, md.nx * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(c->var.front, dim3(md.nseg), dim3(PG_BLK), 0, st, md, c->tp, t, seed, x_dev, logw_dev, c->d_ref, x_new_dev, c->sb[0]);
+    if (c->corrected && !c->aux_buf) HIPCHK(c, hipMalloc(&c->aux_buf, (size_t)md.N * md.nx * sizeof(double)));
+    hipLaunchKernelGGL(c->var.front, dim3(md.nseg), dim3(PG_BLK), 0, st, md, c->tp, t, seed, x_dev, logw_dev, c->d_ref, c->corrected,
+                       c->corrected ? c->aux_buf : x_new_dev, c->sb[0]);
     KCHK(c, "k_front");
     int rc = launch_upper(c, c->sb[0], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(c->back, dim3(md.nseg), dim3(PG_BLK), 0, st, md, t,
-                       pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), x_new_dev, c->sb[0], anc_dev, logw_new_dev);
+    if (c->corrected) {
+        hipLaunchKernelGGL(c->back_corrected, dim3(md.nseg), dim3(PG_BLK), 0, st, md, c->tp, t, seed,
+                           pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), c->aux_buf, c->d_ref, c->sb[0], anc_dev, x_new_dev, logw_new_dev);
+    } else {
+        hipLaunchKernelGGL(c->back, dim3(md.nseg), dim3(PG_BLK), 0, st, md, t,
+                           pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), x_new_dev, c->sb[0], anc_dev, logw_new_dev);
+    }
     KCHK(c, "k_back");
     return PGAS_OK;
 }
@@ -409,6 +421,24 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     c->evp_used = 0;
     if (T == 1) {
         HIPCHK(c, hipMemsetAsync(c->logw_last, 0, N * sizeof(double), st));
+    } else if (c->corrected) {
+        // corrected mode: x_t depends on the ancestors a_t, so the step is a serial chain of three launches on one stream
+        // (transition means + scans, cross-segment scan + reference ancestor, search + propagate + weights)
+        if (!c->aux_buf) HIPCHK(c, hipMalloc(&c->aux_buf, row * sizeof(double)));
+        for (int t = 1; t < T; ++t) {
+            const double* lw_prev = t == 1 ? (const double*)nullptr : (c->logw_trace ? c->logw_trace + (size_t)(t - 1) * N : c->logw_last);
+            double* lw_out = c->logw_trace ? c->logw_trace + (size_t)t * N : c->logw_last;
+            hipLaunchKernelGGL(c->var.front, grid, blk, 0, st, md, c->tp, t, seed, c->x_trace + (size_t)(t - 1) * row, lw_prev, ref_dev + (size_t)t * nx, 1,
+                               c->aux_buf, c->sb[0]);
+            KCHK(c, "k_front");
+            rc = launch_upper(c, c->sb[0], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(c->back_corrected, grid, blk, 0, st, md, c->tp, t, seed, pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t),
+                               c->aux_buf, ref_dev + (size_t)t * nx, c->sb[0], c->anc_trace + (size_t)(t - 1) * N, c->x_trace + (size_t)t * row, lw_out);
+            KCHK(c, "k_back_corrected");
+        }
+        if (c->logw_trace)
+            HIPCHK(c, hipMemcpyAsync(c->logw_last, c->logw_trace + (size_t)(T - 1) * N, N * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else {
         const size_t np = (size_t)md.nseg * PGAS_SEG;
         if (c->profiling) {
@@ -564,6 +594,11 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
     if (option == PGAS_OPT_PROPAGATE_LDS) {
         if (value < 0 || value > 160 * 1024) FAIL(c, PGAS_E_ARG, "pgas_set_option: LDS bytes out of range");
         c->prop_lds = (int)value;
+        return PGAS_OK;
+    }
+    if (option == PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE) {
+        if (value && c->sharded) FAIL(c, PGAS_E_STATE, "pgas_set_option: the corrected mode is not available on a sharded context");
+        c->corrected = value ? 1 : 0;
         return PGAS_OK;
     }
     FAIL(c, PGAS_E_ARG, "pgas_set_option: unknown option %d", option);

@@ -568,14 +568,14 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
 template <int NX, int D, int JIN, int P>
 __device__ __forceinline__ void propagate_particles(const DevModel& md, const TransParams& tp, int t, uint64_t seed,
                                                     const double* __restrict__ ref_t, int seg, const double (&xprev)[PG_PPT][NX],
-                                                    double (&xnew)[PG_PPT][NX], double (&la)[PG_PPT], double (&h)[PG_PPT]) {
+                                                    double (&xnew)[PG_PPT][NX], double (&la)[PG_PPT], double (&h)[PG_PPT],
+                                                    double (&aux)[PG_PPT][NX]) {
     const int tid = threadIdx.x;
     const double* __restrict__ yt = md.y + (size_t)t * md.ny;
     const double* __restrict__ ut = md.u + (size_t)t * md.nu;
     double rf[NX];
 #pragma unroll
     for (int k = 0; k < NX; ++k) rf[k] = ref_t[k];
-    double aux[PG_PPT][NX];
 #pragma unroll
     for (int r0 = 0; r0 < PG_PPT; r0 += P) {
         double xin[P][NX], ax[P][NX];
@@ -645,12 +645,14 @@ __device__ __forceinline__ void store_particles(const DevModel& md, double* __re
 template <int NX, int D, int JIN, int P>
 __device__ __forceinline__ void front_particles(const DevModel& md, const TransParams& tp, int t, uint64_t seed,
                                                 const double* __restrict__ ref_t, int seg, const double (&xprev)[PG_PPT][NX],
-                                                const double (&logw)[PG_PPT], double* __restrict__ x_new,
+                                                const double (&logw)[PG_PPT], int corrected, double* __restrict__ x_new,
                                                 double* __restrict__ laux_out, double (&lw)[2][PG_PPT]) {
     const int tid = threadIdx.x;
-    double xn[PG_PPT][NX], la[PG_PPT], h[PG_PPT];
-    propagate_particles<NX, D, JIN, P>(md, tp, t, seed, ref_t, seg, xprev, xn, la, h);
-    store_particles<NX>(md, x_new, seg, xn);
+    double xn[PG_PPT][NX], la[PG_PPT], h[PG_PPT], aux[PG_PPT][NX];
+    propagate_particles<NX, D, JIN, P>(md, tp, t, seed, ref_t, seg, xprev, xn, la, h, aux);
+    // corrected mode (resample before propagate): hand the transition means to k_back_corrected instead of new states
+    if (corrected) store_particles<NX>(md, x_new, seg, aux);
+    else store_particles<NX>(md, x_new, seg, xn);
 #pragma unroll
     for (int r = 0; r < PG_PPT; ++r) {
         const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
@@ -684,7 +686,7 @@ __device__ __forceinline__ void load_particles(const DevModel& md, const double*
 template <int NX, int D, int JIN, int P>
 __global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, TransParams tp, int t, uint64_t seed,
                                                    const double* __restrict__ x_prev, const double* __restrict__ logw_prev,
-                                                   const double* __restrict__ ref_t, double* __restrict__ x_new, ScanBufs sb) {
+                                                   const double* __restrict__ ref_t, int corrected, double* __restrict__ x_new, ScanBufs sb) {
     __shared__ ScanSmem sm;
     const int seg = blockIdx.x, tid = threadIdx.x;
     double xv[PG_PPT][NX], lwp[PG_PPT], lw[2][PG_PPT];
@@ -694,7 +696,7 @@ __global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, TransParams tp, i
         const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
         lwp[r] = (logw_prev != nullptr && pi < md.N) ? logw_prev[pi] : 0.0;
     }
-    front_particles<NX, D, JIN, P>(md, tp, t, seed, ref_t, seg, xv, lwp, x_new, sb.laux, lw);
+    front_particles<NX, D, JIN, P>(md, tp, t, seed, ref_t, seg, xv, lwp, corrected, x_new, sb.laux, lw);
     segment_scan<2>(sm, lw, seg, sb.nsegp, sb.c1, sb.c2, sb.segm_w, sb.segs_w);
 }
 
@@ -1169,6 +1171,51 @@ __global__ __launch_bounds__(PG_BLK) void k_back(DevModel md, int t, double u1, 
     }
 }
 
+// k_back_corrected: the second half of a step in the CORRECTED mode (resample_before_propagate; quirk Q1 removed):
+//   a = systematic resampling search,  x_new_i = aux[a_i] + L_S z_i  (conditioned particle = ref_t),
+//   logw_new_i = log p(y_t | x_new_i) - l_aux[a_i].
+// aux holds the transition means k_front stored; the noise z_i is the same Philox draw the default mode uses for
+// particle i at time t, so the two modes differ only in which mean the noise is added to.
+template <int NX>
+__global__ __launch_bounds__(PG_BLK) void k_back_corrected(DevModel md, TransParams tp, int t, uint64_t seed, double u1,
+                                                            const double* __restrict__ aux, const double* __restrict__ ref_t, ScanBufs sb,
+                                                            int32_t* __restrict__ anc_out, double* __restrict__ x_new,
+                                                            double* __restrict__ logw_out) {
+    __shared__ BackSmem sm;
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    int anc[PG_PPT];
+    Peers none;
+    none.world = 1;
+    resample_slots(md, sm, u1, sb, none, seg, anc_out, anc);
+    const double* __restrict__ yt = md.y + (size_t)t * md.ny;
+    double z0[PG_PPT], z1[PG_PPT];
+    {
+        pgas_u32x4 w[PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
+            w[r] = pgas_rng_block(seed, PGAS_STREAM_PROP, 0u, (uint32_t)t, (uint64_t)(md.p0 + pi));
+        }
+        pgas_normal_pair_n(w, z0, z1, PG_PPT);
+    }
+    double xn[PG_PPT][NX];
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) {
+        const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
+        const int src = pi < md.N ? anc[r] : 0;
+        const double z[2] = {z0[r], z1[r]};
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            double v = aux[(size_t)src * NX + k];
+#pragma unroll
+            for (int l = 0; l <= k; ++l) v = PGAS_FMA(tp.LS[k * NX + l], z[l], v);
+            xn[r][k] = (md.p0 + pi == md.Ng - 1) ? ref_t[k] : v;
+        }
+        if (pi < md.N) logw_out[pi] = loglik<NX>(md, yt, xn[r]) - sb.laux[src];
+    }
+    store_particles<NX>(md, x_new, seg, xn);
+}
+
 // ------------------------------------------------------------------------------------------
 // The sweep (condSequentialMonteCarlo.__call__, src/PGAS.py:176-228) as two decoupled pipelines.
 //
@@ -1190,8 +1237,8 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
     double xv[PG_PPT][NX];
     load_particles<NX>(md, x_trace + (size_t)(t0 - 1) * row, seg, xv);
     for (int t = t0; t < t1; ++t) {
-        double xn[PG_PPT][NX], la[PG_PPT], h[PG_PPT];
-        propagate_particles<NX, D, JIN, P>(md, tp, t, seed, ref + (size_t)t * NX, seg, xv, xn, la, h);
+        double xn[PG_PPT][NX], la[PG_PPT], h[PG_PPT], aux[PG_PPT][NX];
+        propagate_particles<NX, D, JIN, P>(md, tp, t, seed, ref + (size_t)t * NX, seg, xv, xn, la, h, aux);
         store_particles<NX>(md, x_trace + (size_t)t * row, seg, xn);
         const double* __restrict__ yt = md.y + (size_t)t * md.ny;
 #pragma unroll

@@ -133,6 +133,12 @@ int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample
 #define PGAS_OPT_PROPAGATE_LDS 4 /* bytes of LDS reserved per k_propagate workgroup while overlapping (occupancy cap) */
 #define PGAS_OPT_OVERLAP 3 /* 1 (default): weight recursion on an internal stream, concurrent with k_propagate */
 #define PGAS_OPT_FORCE_SLOW_RESAMPLE 2 /* 1: always use the k_resample + k_upper pair (the path taken when N > 2^20 per device) */
+/* 1: CORRECTED mode, not the reference's behaviour.  src/PGAS.py:131-133 propagates every particle from its own previous
+ * state (`state`, not `state[a_indices]`) although the ancestors are recorded and used for the weights and the
+ * back-trace.  With this option pgas_step / pgas_sweep draw x_t[i] ~ N(A phi(x_{t-1}[a_i]), S) as a particle filter should
+ * (and as src/Algorithm1.py:286-292 does).  Same random numbers, same weight formula; the step becomes a serial chain of
+ * three launches.  Default 0 = reproduce the reference. */
+#define PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE 5
 int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
 
 /* Free functions of src/Filtering.py on the device.  systematic_SISR(key, w) (:6-37): u = the uniform the reference draws

@@ -49,6 +49,8 @@ def lib():
         L.oc_init_state.argtypes = [C.c_void_p, C.c_uint64, dp, dp, dp, dp]
         L.oc_final_index.restype = C.c_int64
         L.oc_final_index.argtypes = [C.c_void_p, C.c_uint64, dp]
+        L.oc_set_corrected.restype = None
+        L.oc_set_corrected.argtypes = [C.c_void_p, C.c_int32]
         L.oc_sweep.restype = C.c_int
         L.oc_sweep.argtypes = [C.c_void_p, C.c_uint64, dp, dp, dp, dp, C.c_double, dp, dp, dp, dp, ip, dp, C.c_int32]
         L.oc_exp_v.argtypes = [dp, dp, C.c_int64]
@@ -160,6 +162,10 @@ class CanonModel:
         )
         if not self._h:
             raise ValueError("oc_model_create rejected the model description")
+
+    def set_corrected(self, on):
+        """CORRECTED mode (resample before propagate, quirk Q1 removed); default off = the reference's behaviour."""
+        lib().oc_set_corrected(self._h, 1 if on else 0)
 
     def __del__(self):
         try:

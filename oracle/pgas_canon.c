@@ -38,6 +38,7 @@ typedef struct {
     int32_t* idx; /* M x D frequencies (reference order, src/BasisFunctions.py:59) */
     double* y;    /* T x ny */
     double* u;    /* T x nu */
+    int32_t corrected; /* 1: propagate from the resampled ancestors (NOT the reference's behaviour, quirk Q1 removed) */
 } oc_model;
 
 /* --------------------------------------------------------------------------- test hooks -- */
@@ -381,6 +382,7 @@ EXPORT int oc_step(const oc_model* m, int32_t t, uint64_t seed, const double* x_
     double* G = (double*)malloc(sizeof(double) * (size_t)(nx * g));
     oc_pack_coeff(m, A, G);
     double* laux = (double*)malloc(sizeof(double) * N);
+    double* auxall = m->corrected ? (double*)malloc(sizeof(double) * (size_t)N * nx) : NULL;
     double* lw1 = (double*)malloc(sizeof(double) * N);
     double* lw2 = (double*)malloc(sizeof(double) * N);
     uint64_t* c1 = (uint64_t*)malloc(sizeof(uint64_t) * N);
@@ -404,15 +406,19 @@ EXPORT int oc_step(const oc_model* m, int32_t t, uint64_t seed, const double* x_
             quad = PGAS_FMA(w, w, quad);
         }
         lw2[p] = lw1[p] + PGAS_FMA(-0.5, quad, cS);                     /* :117 */
-        pgas_rng_normals(seed, PGAS_STREAM_PROP, (uint32_t)t, (uint64_t)p, nx, z);
-        for (int k = 0; k < nx; ++k) {                                  /* :130-133, Q1 */
-            double xv = aux[k];
-            for (int l = 0; l <= k; ++l) xv = PGAS_FMA(LS[k * nx + l], z[l], xv);
-            x_new[(size_t)p * nx + k] = xv;
+        if (m->corrected) {
+            memcpy(auxall + (size_t)p * nx, aux, sizeof(double) * nx);  /* the draw waits for the ancestors */
+        } else {
+            pgas_rng_normals(seed, PGAS_STREAM_PROP, (uint32_t)t, (uint64_t)p, nx, z);
+            for (int k = 0; k < nx; ++k) {                              /* :130-133, Q1: own state, not state[a] */
+                double xv = aux[k];
+                for (int l = 0; l <= k; ++l) xv = PGAS_FMA(LS[k * nx + l], z[l], xv);
+                x_new[(size_t)p * nx + k] = xv;
+            }
         }
         if (dbg_aux) memcpy(dbg_aux + (size_t)p * nx, aux, sizeof(double) * nx);
     }
-    memcpy(x_new + (size_t)(N - 1) * nx, ref_t, sizeof(double) * nx);   /* :134 */
+    if (!m->corrected) memcpy(x_new + (size_t)(N - 1) * nx, ref_t, sizeof(double) * nx);   /* :134 */
 
     for (int b = 0; b < nseg; ++b) {
         int base = b * PGAS_SEG, n = N - base < PGAS_SEG ? N - base : PGAS_SEG;
@@ -442,6 +448,18 @@ EXPORT int oc_step(const oc_model* m, int32_t t, uint64_t seed, const double* x_
         }
         anc[N - 1] = (int32_t)r;
     }
+    if (m->corrected) {   /* corrected mode: x_new_i = aux[a_i] + L_S z_i, same noise as the default mode */
+        for (int p = 0; p < N; ++p) {
+            double z[PGAS_MAX_NX + 1];
+            pgas_rng_normals(seed, PGAS_STREAM_PROP, (uint32_t)t, (uint64_t)p, nx, z);
+            for (int k = 0; k < nx; ++k) {
+                double xv = auxall[(size_t)anc[p] * nx + k];
+                for (int l = 0; l <= k; ++l) xv = PGAS_FMA(LS[k * nx + l], z[l], xv);
+                x_new[(size_t)p * nx + k] = xv;
+            }
+        }
+        memcpy(x_new + (size_t)(N - 1) * nx, ref_t, sizeof(double) * nx);
+    }
     for (int p = 0; p < N; ++p)                                         /* :137-147 */
         logw_new[p] = loglik(m, yt, x_new + (size_t)p * nx) - laux[anc[p]];
 
@@ -451,9 +469,11 @@ EXPORT int oc_step(const oc_model* m, int32_t t, uint64_t seed, const double* x_
     if (dbg_u) { dbg_u[0] = u1; dbg_u[1] = u2; dbg_u[2] = U1.S; dbg_u[3] = U2.S; }
     upper_free(&U1); upper_free(&U2);
     free(G); free(laux); free(lw1); free(lw2); free(c1); free(c2);
-    free(segm1); free(segm2); free(segs1); free(segs2);
+    free(segm1); free(segm2); free(segs1); free(segs2); free(auxall);
     return 0;
 }
+
+EXPORT void oc_set_corrected(oc_model* m, int32_t on) { m->corrected = on ? 1 : 0; }
 
 /* x_0 ~ N(m0, P0), conditioned particle last  (src/PGAS.py:155-174, :194) */
 EXPORT void oc_init_state(const oc_model* m, uint64_t seed, const double* m0, const double* L0,

@@ -234,7 +234,10 @@ class condSequentialMonteCarlo:
         a = a.copy()
         a[-1] = ref_idx  # :127
         Ls = np.linalg.cholesky(np.atleast_2d(error_cov))
-        new_state = aux + z @ Ls.T  # :130-133 (Q1: from `state`, not state[a]; Q6: same Phi)
+        if getattr(self, "resample_before_propagate", False):
+            new_state = aux[a] + z @ Ls.T  # CORRECTED mode (not the reference): propagate state[a], cf. src/Algorithm1.py:286-292
+        else:
+            new_state = aux + z @ Ls.T  # :130-133 (Q1: from `state`, not state[a]; Q6: same Phi)
         new_state[-1] = ref_state  # :134
         new_lw = self.lik(self.y[time], new_state, self.u[time]) - ll_aux[a]  # :137-147
         return new_lw, new_state, a

@@ -259,3 +259,34 @@ def test_tiny_sizes(N, T):
     _eq(X, Xo, "state_trace")
     _eq(ANC[: pb.T - 1], ANCo, "ancestor_trace")
     _eq(traj, trajo.reshape(traj.shape), "trajectory")
+
+
+@pytest.mark.parametrize("name,N", [("smo", 3000), ("toy", 1500), ("veh27", 2500), ("smo", 70000)])
+def test_corrected_mode_bit_exact(name, N):
+    """PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE (corrected mode, not the reference's behaviour): step and whole sweep against the
+    canonical oracle running the same mode."""
+    pb = _problems()[name]()
+    A, S = experiments.initial_params(pb)
+    cm = canon_model(pb, N)
+    cm.set_corrected(True)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn, resample_before_propagate=True)
+    LS, LSinv, cS = cm.chol_parts(S)
+    L0 = np.linalg.cholesky(pb.init_state_cov)
+    x = cm.init_state(SEED, pb.init_state_mean, L0, pb.X_true[0])
+    lw = np.zeros(N)
+    for t in (1, 2, 3):
+        lwc, xc, ac = cm.step(t, SEED, x, lw, A, LS, LSinv, cS, pb.X_true[t])
+        lwg, xg, ag = csmc.step(SEED, t, torch.as_tensor(lw), torch.as_tensor(x), A, S, pb.X_true[t])
+        _eq(ag, ac, f"corrected ancestors t={t}")
+        _eq(xg, xc, f"corrected state t={t}")
+        _eq(lwg, lwc, f"corrected log-weights t={t}")
+        lw, x = lwc, xc
+    traj, X, ANC, lwl = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, L0)
+    tg = csmc(SEED, pb.X_true, A, S)
+    xt, at, lwt, _ = csmc.engine.traces()
+    _eq(at, ANC, "corrected sweep ancestors")
+    _eq(xt, X, "corrected sweep states")
+    _eq(lwt, lwl, "corrected sweep final log-weights")
+    _eq(tg, traj.reshape(tuple(tg.shape)), "corrected sweep trajectory")
+    assert (ANC[:, :-1] != np.arange(N - 1)).any()

@@ -120,3 +120,38 @@ def test_golden_canonical_sweeps():
         assert [float(v).hex() for v in traj.reshape(-1)] == spec["traj_hex"], name
         assert ANC[-1].tolist() == spec["anc_last"] and [int(r.sum()) for r in ANC] == spec["anc_sum"], name
         assert [float(v).hex() for v in lw[:8]] == spec["logw_last_hex"], name
+
+
+@pytest.mark.parametrize("name,N", [("smo", 300), ("veh27", 500)])
+def test_corrected_mode_matches_numpy(name, N):
+    """resample_before_propagate (NOT the reference's behaviour, quirk Q1 removed): x_new = aux[a] + L z in both oracles."""
+    pb = _mk(name)
+    A, S = experiments.initial_params(pb)
+    cm, nm = canon_model(pb, N), numpy_csmc(pb, N)
+    cm.set_corrected(True)
+    nm.resample_before_propagate = True
+    LS, LSinv, cS = cm.chol_parts(S)
+    rand = canon_rand(SEED, N, pb.T, pb.nx)
+    x = cm.init_state(SEED, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov), pb.X_true[0])
+    lw = np.zeros(N)
+    moved = 0
+    for t in range(1, 6):
+        lwc, xc, ac, dbg = cm.step(t, SEED, x, lw, A, LS, LSinv, cS, pb.X_true[t], debug=True)
+        lwn, xn, an = nm.step(rand["u_resample"][t], rand["u_ancestor"][t], rand["z"][t], t, lw, x, A, S, pb.X_true[t])
+        same = ac == an
+        assert same.mean() > 0.99
+        assert np.abs(xc[same] - xn[same]).max() <= 1e-12 * max(1.0, np.abs(xn).max())
+        assert np.abs(lwc[same] - lwn[same]).max() <= 1e-8 * max(1.0, np.abs(lwn).max())
+        # the new state is the ancestor's mean plus this particle's noise
+        Ls = np.linalg.cholesky(S)
+        assert np.allclose(xc[:-1], dbg["aux"][ac[:-1]] + rand["z"][t][:-1] @ Ls.T, rtol=1e-12, atol=1e-14)
+        assert np.array_equal(xc[-1], pb.X_true[t])
+        moved += int((ac[:-1] != np.arange(N - 1)).sum())
+        lw, x = lwc, xc
+    assert moved > 0   # otherwise the test would not distinguish the two modes
+    # and the default mode of the same model differs
+    cm.set_corrected(False)
+    _, xd, ad = cm.step(5, SEED, x, lw, A, LS, LSinv, cS, pb.X_true[5])
+    cm.set_corrected(True)
+    _, xk, ak = cm.step(5, SEED, x, lw, A, LS, LSinv, cS, pb.X_true[5])
+    assert np.array_equal(ad, ak) and not np.array_equal(xd, xk)

@@ -10,7 +10,8 @@ cfgs = (("SMO M=41 (2-D)", lambda: experiments.smo_pgas(T=200)), ("EMPS M=729 (3
 for name, mk in [c for c in cfgs if os.environ.get("ONLY", "") in c[0]]:
     pb = mk()
     A, S = experiments.initial_params(pb)
-    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn,
+                                             resample_before_propagate=bool(os.environ.get('CORRECTED')))
     if os.environ.get("NO_OVERLAP"):
         csmc.engine.set_option(3, 0)
     if os.environ.get("CHUNK"):
