@@ -46,3 +46,42 @@ def prior_mniw_calcStatistics(y, basis):
     y = np.atleast_1d(np.asarray(y, dtype=np.float64))
     basis = np.atleast_1d(np.asarray(basis, dtype=np.float64))
     return np.outer(basis, y), np.outer(basis, basis), np.outer(y, y), 1
+
+
+def prior_mniw_Predictive(mean, col_cov, row_scale, df, basis):
+    """Matrix-t predictive parameters at `basis` (n_b, M) [BI:64-89]: (mean, col_scale, row_scale / df', df' = df + 1 - n)."""
+    basis = np.atleast_2d(np.asarray(basis, dtype=np.float64))
+    col_cov = np.atleast_2d(np.asarray(col_cov, dtype=np.float64))
+    row_scale = np.atleast_2d(np.asarray(row_scale, dtype=np.float64))
+    df = df + 1 - row_scale.shape[0]
+    pred_mean = np.squeeze(basis @ np.atleast_2d(np.asarray(mean, dtype=np.float64)).T)
+    col_scale = basis @ col_cov @ basis.T + np.eye(basis.shape[0])
+    return pred_mean, col_scale, row_scale / df, df
+
+
+def prior_mniw_drawPred(key, mean, col_scale, row_scale, df):
+    """One draw from the matrix-t predictive [BI:92-108]: mean + chol(row) t chol(col)^T with t ~ Student-t(df), one variate per
+    row dimension.  `key` is a pgas_amd.random key (own Philox streams: the reference's jax.random.t stream is not reproducible
+    here); t = z / sqrt(chi2(df) / df)."""
+    from . import random as prng
+
+    Lc = np.linalg.cholesky(np.atleast_2d(np.asarray(col_scale, dtype=np.float64)))
+    Lr = np.linalg.cholesky(np.atleast_2d(np.asarray(row_scale, dtype=np.float64)))
+    n = Lr.shape[0]
+    kz, kc = prng.split(prng.as_key(key), 2)
+    t = prng.normal(kz, (n,)) / np.sqrt(prng.chisquare(kc, np.full(n, float(df))) / float(df))
+    return np.asarray(mean, dtype=np.float64) + np.squeeze(np.einsum("ij,j,jk->ik", Lr, t, Lc.T))
+
+
+def prior_mniw_log_base_measure(T_0, T_1, T_2, T_3):
+    """Log base measure of the MNIW family in natural parameters [BI:111-124]."""
+    from scipy.special import multigammaln
+
+    T_0 = np.asarray(T_0, dtype=np.float64)
+    T_1 = np.asarray(T_1, dtype=np.float64)
+    T_2 = np.atleast_2d(np.asarray(T_2, dtype=np.float64))
+    n, m = T_2.shape[0], T_1.shape[0]
+    Psi = T_2 - T_0.T @ _solve_spd(T_1, T_0)
+    nu = T_3
+    return (-0.5 * n * m * np.log(2 * np.pi) + 0.5 * n * np.log(np.linalg.det(T_1)) - 0.5 * nu * n * np.log(2)
+            - multigammaln(nu / 2, n) + np.log(np.linalg.det(Psi)) * nu / 2)

@@ -13,7 +13,10 @@ from .BayesianInferrence import (  # noqa: F401
     prior_mniw_2naturalPara,
     prior_mniw_2naturalPara_inv,
     prior_mniw_calcStatistics,
+    prior_mniw_drawPred,
+    prior_mniw_log_base_measure,
     prior_mniw_mean,
+    prior_mniw_Predictive,
 )
 from .descriptors import BasisMap, GaussianLikelihood, HilbertBasis  # noqa: F401
 from .Filtering import reconstruct_trajectory, systematic_SISR  # noqa: F401
@@ -30,6 +33,9 @@ __all__ = [
     "prior_mniw_2naturalPara_inv",
     "prior_mniw_calcStatistics",
     "prior_mniw_mean",
+    "prior_mniw_Predictive",
+    "prior_mniw_drawPred",
+    "prior_mniw_log_base_measure",
     "random",
     "systematic_SISR",
     "reconstruct_trajectory",

@@ -1,0 +1,53 @@
+"""Whole Gibbs sampler on the device (PGAS.__call__, src/PGAS.py:345-397) on the reference's Toy problem."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _driver(name="Toy_Example_Simulation"):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", name + ".py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("corrected", [False, True])
+def test_toy_posterior_mean_approaches_true_function(corrected):
+    """SURVEY 8c KAT 7: the Toy PGAS posterior mean of A phi(x) moves from the prior (zero) towards 10 sinc(x/7) on the data
+    range.  Statistical test, and a weak one by nature: 39 transitions, process and measurement noise variance 4 each.
+    Calibration (tools/toy_probe.py and the literal NumPy restatement run through the same Gibbs loop with NumPy's RNG):
+    RMSE on the central data range 3.67 (this engine), 3.68 (NumPy restatement), 1.10 given the TRUE states, 6.3 for the
+    prior mean -- the engine reproduces the reference algorithm's statistics, which is what is asserted."""
+    res = _driver().run(iterations=300, particles=200, resample_before_propagate=corrected)
+    assert res["pgas_Sigma_X"].shape == (40, 300, 1) and res["pgas_log_likelihood"].shape == (40, 300)
+    assert np.isfinite(res["pgas_Sigma_X"]).all() and np.isfinite(res["pgas_log_likelihood"]).all()
+    X = res["X"][:, 0]
+    lo, hi = np.percentile(X, 10), np.percentile(X, 90)
+    near = (res["x_plot"] > lo) & (res["x_plot"] < hi)
+    err = res["pgas_fcn_mean"][near] - res["fx_true_plot"][near]
+    rmse = float(np.sqrt(np.mean(err ** 2)))
+    print("toy posterior RMSE on the central data range:", rmse, "corrected" if corrected else "reference mode")
+    rmse_prior = float(np.sqrt(np.mean(res["fx_true_plot"][near] ** 2)))
+    assert rmse < 4.5 and rmse < 0.75 * rmse_prior
+    # the sampled trajectories follow the data: the posterior-mean trajectory correlates with the simulated truth
+    xm = res["pgas_Sigma_X"][1:, 100:, 0].mean(axis=1)
+    corr = float(np.corrcoef(xm, X[1:])[0, 1])
+    print("correlation of the posterior-mean trajectory with the truth:", corr)
+    assert corr > 0.5
+
+
+def test_emps_driver_fields_and_tracking():
+    """examples/EMPS_Simulation.py (PGAS part of the reference driver, synthetic data): field names and shapes of the .mat
+    dictionary (EMPS_Simulation.py:128-160) and a sanity bound on the sampled positions (measurement noise std 1e-2)."""
+    res = _driver("EMPS_Simulation").run(iterations=4, particles=256, steps=300)
+    assert res["offline_Sigma_X_PGAS"].shape == (300, 4, 2) and res["offline_log_likelihood_PGAS"].shape == (300, 4)
+    assert res["PGAS_mean"].shape == (2, 729) and res["PGAS_T1"].shape == (729, 729) and res["PGAS_T3"] == res["prior_T3"] + 299
+    assert np.isfinite(res["offline_Sigma_X_PGAS"]).all()
+    err = res["offline_Sigma_X_PGAS"][:, -1, 0] - res["X"][:, 0]
+    assert np.sqrt(np.mean(err ** 2)) < 0.05

@@ -77,3 +77,30 @@ def test_experiment_definitions():
     v = experiments.vehicle_pgas(T=300)
     assert v.basis_fcn.basis.M == 729 and v.observations.shape == (300, 2) and v.inputs.shape == (300, 2)
     assert np.all(v.inputs[:, 1] == 11.0) and np.abs(v.inputs[:, 0]).max() < 0.25
+
+
+def test_predictive_and_log_base_measure_match_restatement():
+    """BI:64-89 and :111-124 (only used by the drivers' post-processing and by Algorithm1/3)."""
+    rng = np.random.default_rng(11)
+    M, n = 9, 2
+    mean = rng.standard_normal((n, M))
+    V = rng.standard_normal((M, M)); V = V @ V.T + M * np.eye(M)
+    Psi = np.array([[2.0, 0.3], [0.3, 1.0]])
+    basis = rng.standard_normal((5, M))
+    got = pgas_amd.prior_mniw_Predictive(mean, V, Psi, 7, basis)
+    ref = o.prior_mniw_Predictive(mean, V, Psi, 7, basis)
+    for g, r in zip(got, ref):
+        assert np.allclose(g, r, rtol=1e-13)
+    assert got[3] == 7 + 1 - n and np.allclose(got[1], basis @ V @ basis.T + np.eye(5))
+    eta = pgas_amd.prior_mniw_2naturalPara(mean, V, Psi, 7)
+    assert np.isclose(pgas_amd.prior_mniw_log_base_measure(*eta), o.prior_mniw_log_base_measure(*eta), rtol=1e-12)
+
+
+def test_draw_pred_is_a_scaled_student_t():
+    k = prng.key(99)
+    row, col, df = np.array([[4.0]]), np.array([[2.25]]), 5
+    d = np.array([pgas_amd.prior_mniw_drawPred(s, np.array([1.5]), col, row, df) for s in prng.split(k, 4000)]).reshape(-1)
+    # mean 1.5, variance row * col * df / (df - 2)
+    assert abs(d.mean() - 1.5) < 0.2
+    assert abs(d.var() / (4.0 * 2.25 * df / (df - 2)) - 1) < 0.25
+    assert np.array_equal(pgas_amd.prior_mniw_drawPred(k, np.array([1.5]), col, row, df), pgas_amd.prior_mniw_drawPred(k, np.array([1.5]), col, row, df))
