@@ -20,10 +20,17 @@ from .BayesianInferrence import (  # noqa: F401
 )
 from .descriptors import BasisMap, GaussianLikelihood, HilbertBasis  # noqa: F401
 from .Filtering import reconstruct_trajectory, systematic_SISR  # noqa: F401
+from .Algorithm1 import Algorithm1, Algorithm3  # noqa: F401
+from .Algorithm2 import Algorithm2  # noqa: F401
 from .PGAS import PGAS, condSequentialMonteCarlo  # noqa: F401
+from .StateSpaceModel import StateSpaceModel  # noqa: F401
 
 __all__ = [
     "PGAS",
+    "Algorithm1",
+    "Algorithm2",
+    "Algorithm3",
+    "StateSpaceModel",
     "condSequentialMonteCarlo",
     "generate_Hilbert_BasisFunction",
     "HilbertBasis",

@@ -38,6 +38,7 @@ EXPORTS = [
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
+    "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_mniw_solve", "pgas_m_stats_gather_update",
 ]
 
 _lib = None
@@ -99,6 +100,17 @@ def load():
     L.pgas_ipc_export.argtypes = [vp, i32, C.c_char_p]
     L.pgas_ipc_open.restype = C.c_int
     L.pgas_ipc_open.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
+    u32 = C.c_uint32
+    L.pgas_m_rng_uniform.restype = C.c_double
+    L.pgas_m_rng_uniform.argtypes = [u64, u32, u32]
+    L.pgas_m_rng_normal.restype = C.c_int
+    L.pgas_m_rng_normal.argtypes = [vp, u64, u32, u32, i64, i64, i32, vp, vp]
+    L.pgas_m_rng_student_t.restype = C.c_int
+    L.pgas_m_rng_student_t.argtypes = [vp, u64, u32, u32, i64, i64, vp, vp, vp]
+    L.pgas_m_mniw_solve.restype = C.c_int
+    L.pgas_m_mniw_solve.argtypes = [vp, i64, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_stats_gather_update.restype = C.c_int
+    L.pgas_m_stats_gather_update.argtypes = [vp, i64, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
     return L
 
@@ -346,3 +358,70 @@ class Engine:
         T2 = torch.empty((self.nx, self.nx), dtype=torch.float64, device=self.device)
         self._chk(self.lib.pgas_suffstats(self._h, traj.data_ptr(), T0.data_ptr(), T1.data_ptr(), T2.data_ptr(), self._stream()), "pgas_suffstats")
         return T0, T1, T2, float(self.T - 1)
+
+
+class MarginalOps:
+    """Device primitives of the marginalised family (include/pgas_marginal.h) for N particles on one device: Philox normals /
+    uniforms / Student-t variates, batched MNIW solves, statistics gather + update, systematic resampling.  Hand-written HIP
+    through the C ABI; there is no CPU path."""
+
+    def __init__(self, N, device=None):
+        self.eng = Engine.utility(int(N), device)
+        self.N, self.device, self.lib = int(N), self.eng.device, self.eng.lib
+
+    def _ptr(self, t):
+        return 0 if t is None else t.data_ptr()
+
+    def _vec(self, n=None, cols=None):
+        shape = (self.N if n is None else n,) if cols is None else (self.N if n is None else n, cols)
+        return torch.empty(shape, dtype=torch.float64, device=self.device)
+
+    def uniform(self, seed, stream, t):
+        return float(self.lib.pgas_m_rng_uniform(int(seed), int(stream), int(t)))
+
+    def normal(self, seed, stream, t, ncol):
+        out = self._vec(cols=int(ncol))
+        self.eng._chk(self.lib.pgas_m_rng_normal(self.eng._h, int(seed), int(stream), int(t), 0, self.N, int(ncol), out.data_ptr(), self.eng._stream()),
+                      "pgas_m_rng_normal")
+        return out
+
+    def student_t(self, seed, stream, t, nu):
+        nu = nu.to(device=self.device, dtype=torch.float64).contiguous()
+        out = self._vec()
+        self.eng._chk(self.lib.pgas_m_rng_student_t(self.eng._h, int(seed), int(stream), int(t), 0, self.N, nu.data_ptr(), out.data_ptr(),
+                                                    self.eng._stream()), "pgas_m_rng_student_t")
+        return out
+
+    def mniw_solve(self, P0, P1, T0, T1, scale=1.0, anc=None, R0=None, R1=None, phi=None, want=("m", "c", "q", "logdet")):
+        """eta0 = P0 + scale T0[anc] (+R0), eta1 = P1 + scale T1[anc] (+R1) per particle -> dict of (n,) tensors (see pgas_m_mniw_solve)."""
+        n, M = T0.shape[0], T0.shape[1]
+        out = {k: self._vec(n) for k in want}
+        a = None if anc is None else anc.to(device=self.device, dtype=torch.int32).contiguous()
+        for arr in (P0, P1, T0, T1, R0, R1, phi):
+            if arr is not None and not (arr.is_contiguous() and arr.dtype == torch.float64 and arr.device == self.device):
+                raise ValueError("mniw_solve: operands must be contiguous fp64 tensors on the engine's device")
+        if a is not None and (a.numel() != n or int(a.min()) < 0 or int(a.max()) >= n):
+            raise ValueError("mniw_solve: ancestor indices out of range")
+        self.eng._chk(self.lib.pgas_m_mniw_solve(self.eng._h, n, M, float(scale), self._ptr(a), P0.data_ptr(), P1.data_ptr(), T0.data_ptr(), T1.data_ptr(),
+                                                 self._ptr(R0), self._ptr(R1), self._ptr(phi), self._ptr(out.get("m")), self._ptr(out.get("c")),
+                                                 self._ptr(out.get("q")), self._ptr(out.get("logdet")), self.eng._stream()), "pgas_m_mniw_solve")
+        return out
+
+    def stats_gather_update(self, scale, anc, T, phi, xi):
+        """T = (T0 (n,M), T1 (n,M,M), T2 (n,), T3 (n,)) -> scale * T[anc] + statistics of (xi, phi); new tensors."""
+        T0, T1, T2, T3 = T
+        n, M = T0.shape
+        out = (torch.empty_like(T0), torch.empty_like(T1), torch.empty_like(T2), torch.empty_like(T3))
+        a = None if anc is None else anc.to(device=self.device, dtype=torch.int32).contiguous()
+        if a is not None and (a.numel() != n or int(a.min()) < 0 or int(a.max()) >= n):
+            raise ValueError("stats_gather_update: ancestor indices out of range")
+        if phi.shape != (n, M) or xi.numel() != n or T1.shape != (n, M, M):
+            raise ValueError("stats_gather_update: operand shapes do not match (n, M)")
+        self.eng._chk(self.lib.pgas_m_stats_gather_update(self.eng._h, n, M, float(scale), self._ptr(a), T0.data_ptr(), T1.data_ptr(), T2.data_ptr(),
+                                                          T3.data_ptr(), phi.contiguous().data_ptr(), xi.contiguous().data_ptr(), out[0].data_ptr(),
+                                                          out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), self.eng._stream()),
+                      "pgas_m_stats_gather_update")
+        return out
+
+    def systematic_resample(self, u, logw):
+        return self.eng.systematic_resample(u, logw)

@@ -13,6 +13,8 @@
 #include "../../include/pgas_hip.h"
 #include "pgas_kernels.hip.h"
 #include "pgas_suffstats.hip.h"
+#include "pgas_marginal.hip.h"
+#include "../../include/pgas_marginal.h"
 
 #ifndef PG_W28
 #define PG_W28 2
@@ -71,6 +73,7 @@ struct pgas_ctx {
     backc_fn back_corrected = nullptr;
     int corrected = 0;          // PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE: propagate from the resampled ancestors (quirk Q1 removed)
     double* aux_buf = nullptr;  // (N, nx) transition means of the current step, corrected mode only
+    int32_t* d_fail = nullptr;  // failure counter of pgas_m_mniw_solve
     init_fn init = nullptr;
     basis_fn basis = nullptr;
     // device tables
@@ -283,7 +286,7 @@ void pgas_destroy(pgas_ctx* c) {
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
     hipFree(c->segm_g[0]); hipFree(c->segm_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
-    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf);
+    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (hipEvent_t e : c->evp) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
@@ -849,3 +852,65 @@ int pgas_suffstats(pgas_ctx* c, const double* traj_dev, double* T0_dev, double* 
 }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------------------ marginalised family (pgas_marginal.h)
+double pgas_m_rng_uniform(uint64_t seed, uint32_t stream, uint32_t t) { return pgas_rng_uniform(seed, stream, t); }
+
+int pgas_m_rng_normal(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, int32_t ncol, double* out, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!out || n < 0 || ncol < 1 || ncol > 8) FAIL(c, PGAS_E_ARG, "pgas_m_rng_normal: bad argument (n = %lld, ncol = %d)", (long long)n, ncol);
+    if (n == 0) return PGAS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_rng_normal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, p0, n, ncol, out);
+    KCHK(c, "k_rng_normal");
+    return PGAS_OK;
+}
+
+int pgas_m_rng_student_t(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu, double* out, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!out || !nu || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_rng_student_t: bad argument");
+    if (n == 0) return PGAS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_rng_student_t, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, p0, n, nu, out);
+    KCHK(c, "k_rng_student_t");
+    return PGAS_OK;
+}
+
+int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int32_t* anc, const double* P0, const double* P1, const double* T0, const double* T1,
+                      const double* R0, const double* R1, const double* phi, double* m, double* cc, double* q, double* logdet, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!P0 || !P1 || !T0 || !T1 || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: NULL argument");
+    if (M < 1 || M > PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: M = %d outside [1, %d]", M, PG_MN_MAXM);
+    if ((R0 == nullptr) != (R1 == nullptr)) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: R0 and R1 must be given together");
+    if (n == 0) return PGAS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)sh;
+    if (!c->d_fail) HIPCHK(c, hipMalloc(&c->d_fail, sizeof(int32_t)));
+    HIPCHK(c, hipMemsetAsync(c->d_fail, 0, sizeof(int32_t), st));
+    const size_t per = (size_t)M * (M | 1) * sizeof(double);
+    int waves = (int)((60 * 1024) / per);
+    waves = waves > 4 ? 4 : waves < 1 ? 1 : waves;
+    hipLaunchKernelGGL(k_mniw_solve, dim3((unsigned)((n + waves - 1) / waves)), dim3(64 * waves), waves * per, st, n, M, scale, anc, P0, P1, T0, T1, R0, R1,
+                       phi, m, cc, q, logdet, c->d_fail);
+    KCHK(c, "k_mniw_solve");
+    int32_t bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, c->d_fail, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    if (bad) FAIL(c, PGAS_E_STATE, "pgas_m_mniw_solve: %d of %lld matrices eta1 are not positive definite", bad, (long long)n);
+    return PGAS_OK;
+}
+
+int pgas_m_stats_gather_update(pgas_ctx* c, int64_t n, int32_t M, double scale, const int32_t* anc, const double* T0i, const double* T1i,
+                               const double* T2i, const double* T3i, const double* phi, const double* xi, double* T0o, double* T1o, double* T2o,
+                               double* T3o, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!T0i || !T1i || !T2i || !T3i || !phi || !xi || !T0o || !T1o || !T2o || !T3o || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: NULL argument");
+    if (T0i == T0o || T1i == T1o || T2i == T2o || T3i == T3o) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: input and output alias");
+    if (M < 1 || M > 2 * PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: M = %d outside [1, %d]", M, 2 * PG_MN_MAXM);
+    if (n == 0) return PGAS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_stats_gather_update, dim3((unsigned)n), dim3(256), 0, (hipStream_t)sh, n, M, scale, anc, T0i, T1i, T2i, T3i, phi, xi, T0o, T1o, T2o, T3o);
+    KCHK(c, "k_stats_gather_update");
+    return PGAS_OK;
+}

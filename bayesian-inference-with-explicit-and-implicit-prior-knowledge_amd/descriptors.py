@@ -69,6 +69,31 @@ class BasisMap:
             v = np.concatenate([v, np.atleast_1d(np.asarray(input, dtype=np.float64)).reshape(-1)])
         return self.basis(v[self.sel] / self.div)
 
+    def batch(self, state, input=None):
+        """Batched evaluation for the marginalised family (Algorithm1/2/3): state (N, n_x) NumPy array or torch tensor, input (n_u,)
+        or None -> (N, M) of the same kind.  phi = prod_d sqrt(1/L_d) sin(pi j_d (v_d/div_d - center_d + L_d) / size_d)
+        (src/BasisFunctions.py:77-80)."""
+        b = self.basis
+        if isinstance(state, np.ndarray):
+            v = state.reshape(state.shape[0], -1)
+            if input is not None and np.size(input):
+                v = np.concatenate([v, np.broadcast_to(np.asarray(input, dtype=np.float64).reshape(1, -1), (v.shape[0], np.size(input)))], axis=1)
+            ang = np.pi * b.indices[None, :, :] * ((v[:, self.sel] / self.div - b.center + b.L) / b.size)[:, None, :]
+            return np.prod(np.sqrt(1.0 / b.L) * np.sin(ang), axis=2)
+        import torch
+
+        v = state.reshape(state.shape[0], -1)
+        if input is not None and input.numel():
+            v = torch.cat([v, input.reshape(1, -1).expand(v.shape[0], -1)], dim=1)
+        key = v.device
+        if getattr(self, "_tcache", None) is None or self._tcache[0] != key:
+            tt = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=v.device)  # noqa: E731
+            self._tcache = (key, torch.as_tensor(self.sel.astype(np.int64), device=v.device), tt(self.div), tt(b.center), tt(b.L), tt(b.size),
+                            tt(b.indices.astype(np.float64)), tt(np.sqrt(1.0 / b.L)))
+        _, sel, div, center, L, size, idx, amp = self._tcache
+        ang = np.pi * idx[None, :, :] * ((v[:, sel] / div - center + L) / size)[:, None, :]
+        return torch.prod(amp * torch.sin(ang), dim=2)
+
     # engine tables: r_d = v[sel_d] * alpha_d + beta_d
     @property
     def alpha(self):

@@ -178,3 +178,88 @@ def initial_params(problem: Problem):
     e0, e1, e2, e3 = problem.GP_prior
     mean, _, row_scale, df = prior_mniw_2naturalPara_inv(e0 + Phi.T @ Xp, e1 + Phi.T @ Phi, e2 + Xp.T @ Xp, e3 + (T - 1))
     return np.ascontiguousarray(mean), np.atleast_2d(row_scale) / df
+
+
+# ================================================================ marginalised family (Algorithm1/2/3): problem definitions
+@dataclass
+class MarginalProblem:
+    """One configuration of the reference's Algorithm1/Algorithm2 drivers.  `model(xp)` returns (transition_model, output_model)
+    written against the array namespace xp (numpy or torch), batched over particles: the SAME arithmetic for the device mirror
+    (pgas_amd.StateSpaceModel) and for the NumPy restatement used by the tests."""
+    name: str
+    observations: np.ndarray
+    inputs: np.ndarray
+    process_noise: np.ndarray
+    output_noise: np.ndarray
+    init_state_mean: np.ndarray
+    init_state_cov: np.ndarray
+    init_int_var_mean: list
+    init_int_var_cov: list
+    GP_prior: list
+    basis: list                 # BasisMap per interface variable; basis[i].batch(state, input)
+    forgetting_factor: float
+    model: object
+    X_true: np.ndarray
+    int_var_true: list
+
+    @property
+    def T(self):
+        return self.observations.shape[0]
+
+    def ssm(self, cls, xp):
+        f, g = self.model(xp)
+        return cls(process_noise=self.process_noise, output_noise=self.output_noise, transition_model=f, output_model=g)
+
+    def basis_fcn(self):
+        return [lambda state, input, b=b: b.batch(state, input) for b in self.basis]
+
+
+def smo_marginal(T=750, seed=12345678):
+    """src/SingleMassOscillator.py:14-167: the spring-damper force F_sd is the latent function, interface variable of the RK4 model."""
+    m, dt = 0.2, 0.02                                      # :17, :78
+    pg = smo_pgas(T=T, seed=seed)                          # same data and basis (M = 41 on [-7.5, 7.5]^2)
+    X = pg.X_true
+    c1, c2, d1, d2 = 5.0, 2.0, 0.4, 0.4
+    F_sd = c1 * X[:, 0] + c2 * X[:, 0] ** 3 + d1 * X[:, 1] / (1 + d2 * X[:, 1] * np.tanh(X[:, 1]))   # :24-29
+
+    def model(xp):
+        def dx(x, F, F_sd):                                # :32-33
+            return xp.stack([x[:, 1], (-F_sd + F) / m], 1)
+
+        def f_x(state, input, *int_var):                   # :36-44, :104-106
+            F, Fs = input.reshape(-1)[0], int_var[0].reshape(-1)
+            k1 = dx(state, F, Fs)
+            k2 = dx(state + dt / 2.0 * k1, F, Fs)
+            k3 = dx(state + dt / 2.0 * k2, F, Fs)
+            k4 = dx(state + dt * k3, F, Fs)
+            return state + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+        def f_y(state, input, *int_var):                   # :47-48, :107
+            return state[:, 0:1]
+
+        return f_x, f_y
+
+    basis = pg.basis_fcn.basis
+    sd = np.diag(np.linalg.inv(pg.GP_prior[1]))            # eta1 = diag(sd)^-1
+    prior = prior_mniw_2naturalPara(np.zeros((1, basis.M)), np.diag(sd), np.eye(1), 3)   # :63-68
+    return MarginalProblem("SMO", pg.observations, pg.inputs.reshape(-1, 1), np.diag([5e-8, 5e-9]), np.array([[1e-3]]), np.array([0.0, 0.0]),
+                           np.diag([1e-4, 1e-4]), [np.array([0.0])], [np.diag([1e-12])], [prior], [basis.on([0, 1])], 0.999, model, X, [F_sd])
+
+
+def toy_marginal(T=40, seed=12345678):
+    """src/Toy_Example.py:14-128: no model knowledge, the transition IS the latent function (x_t = xi_{t-1})."""
+    pt = toy(T=T, seed=seed)
+
+    def model(xp):
+        def f_x(state, input, *int_var):                   # :69
+            return int_var[0].reshape(-1, 1)
+
+        def f_y(state, input, *int_var):                   # :70 with f_y = identity (:22-23)
+            return int_var[0].reshape(-1, 1)
+
+        return f_x, f_y
+
+    X = pt.X_true
+    fx_true = 10 * np.sinc(X[:, 0] / 7)
+    return MarginalProblem("Toy", pt.observations, pt.inputs, np.zeros((1, 1)), np.diag([4.0]), np.array([0.0]), np.diag([1e-4]),
+                           [np.array([10 * np.sinc(0.0)])], [np.diag([4.0])], [pt.GP_prior], [pt.basis_fcn], 1.0, model, X, [fx_true])

@@ -57,4 +57,46 @@ PGAS_HD void pgas_rng_normals(uint64_t seed, uint32_t stream, uint32_t t, uint64
     }
 }
 
+/* ---- streams of the marginalised family (reference src/Algorithm1.py, src/Algorithm3.py); int-var index i < 8 is added
+ * to the *_INTVAR streams */
+#define PGAS_STREAM_M_INIT_STATE 16u  /* x_0 ~ N(m0, P0)                      (src/Algorithm1.py:139-145) */
+#define PGAS_STREAM_M_STATE 17u       /* process noise of SSM.draw_state      (src/StateSpaceModel.py:67-74) */
+#define PGAS_STREAM_M_RESAMPLE 18u    /* u of systematic_SISR                 (src/Algorithm1.py:346-347) */
+#define PGAS_STREAM_M_ANCESTOR 19u    /* u of the reference ancestor draw     (src/Algorithm3.py:119-122) */
+#define PGAS_STREAM_M_FINAL 20u       /* u of the final index                 (src/Algorithm3.py:287) */
+#define PGAS_STREAM_M_INIT_INTVAR 24u /* xi_0 ~ N(mean, cov)                  (src/Algorithm1.py:146-153) */
+#define PGAS_STREAM_M_INTVAR 32u      /* Student-t of prior_mniw_drawPred     (src/BayesianInferrence.py:104) */
+
+/* Gamma(a, 1) variate of particle p at (stream, t) by Marsaglia-Tsang squeeze-free rejection; attempt k consumes Philox
+ * draws 1 + 2k (candidate normal) and 2 + 2k (acceptance uniform, boost uniform); a < 1 uses G(a) = G(a+1) U^(1/a).
+ * Built from the deterministic primitives only, so host and device agree bit for bit. */
+PGAS_HD double pgas_rng_gamma(uint64_t seed, uint32_t stream, uint32_t t, uint64_t particle, double a) {
+    const double a1 = a < 1.0 ? a + 1.0 : a;
+    const double d = a1 - 1.0 / 3.0;
+    const double c = 1.0 / sqrt(9.0 * d);
+    double g = d;
+    double boost = 1.0;
+    for (uint32_t k = 0; k < 32u; ++k) {
+        double x, spare;
+        pgas_normal_pair(pgas_rng_block(seed, stream, 1u + 2u * k, t, particle), &x, &spare);
+        const pgas_u32x4 w = pgas_rng_block(seed, stream, 2u + 2u * k, t, particle);
+        const double u = pgas_u52(w.v[0], w.v[1]);
+        if (k == 0u && a < 1.0) boost = pgas_exp(pgas_log(pgas_u52(w.v[2], w.v[3])) / a);
+        double v = PGAS_FMA(c, x, 1.0);
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        g = d * v;
+        if (pgas_log(u) < PGAS_FMA(0.5 * x, x, d) - g + d * pgas_log(v)) break;
+    }
+    return g * boost;
+}
+
+/* Student-t(nu) variate: z sqrt((nu/2) / G), G ~ Gamma(nu/2, 1) (= z / sqrt(chi2_nu / nu)); z is the first normal of draw 0 */
+PGAS_HD double pgas_rng_student_t(uint64_t seed, uint32_t stream, uint32_t t, uint64_t particle, double nu) {
+    double z, spare;
+    pgas_normal_pair(pgas_rng_block(seed, stream, 0u, t, particle), &z, &spare);
+    const double a = 0.5 * nu;
+    return z * sqrt(a / pgas_rng_gamma(seed, stream, t, particle, a));
+}
+
 #endif /* PGAS_CANON_H */

@@ -1,0 +1,53 @@
+/* pgas_marginal.h -- C ABI of the device primitives behind the MARGINALISED family (reference src/Algorithm1.py,
+ * src/Algorithm3.py, src/Algorithm2.py).  Same conventions as pgas_hip.h: return 0 = ok, error
+ * text through pgas_last_error(ctx), device pointers of fp64 / int32 arrays, work enqueued on the caller's stream.  `ctx` is
+ * any context of the target device (the host mirror uses the utility context of pgas_amd/_lib.py); it supplies the device and
+ * the error channel only.
+ *
+ * The reference maps per-particle functions with jax.vmap; these entry points are the batched bodies of
+ *   jax.random.normal / jax.random.t                                    src/StateSpaceModel.py:67, src/BayesianInferrence.py:104
+ *   BI.prior_mniw_mean + einsum            (auxiliary interface variable) src/Algorithm1.py:211-231
+ *   BI.prior_mniw_2naturalPara_inv + BI.prior_mniw_Predictive            src/Algorithm1.py:251-262, BI:35-45, :64-89
+ *   BI.prior_mniw_log_base_measure                                       src/Algorithm3.py:95-108, BI:111-124
+ *   forgetting, ancestor gather and BI.prior_mniw_calcStatistics update  src/Algorithm1.py:317-320, :358-377
+ * for a scalar interface variable (n = 1: every instantiation in the reference). */
+#ifndef PGAS_MARGINAL_H
+#define PGAS_MARGINAL_H
+
+#include "pgas_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The scalar uniform of (seed, stream, t): host value, identical to what the device kernels would draw (pgas_canon.h). */
+double pgas_m_rng_uniform(uint64_t seed, uint32_t stream, uint32_t t);
+
+/* out (n, ncol): normals of particles p0 .. p0+n at (stream, t); ncol <= 8. */
+int pgas_m_rng_normal(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, int32_t ncol,
+                      double* out_dev, void* stream_handle);
+
+/* out (n): Student-t(nu[p]) variates (z / sqrt(chi2_nu / nu), Marsaglia-Tsang gamma sampler on the same Philox streams). */
+int pgas_m_rng_student_t(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu_dev,
+                         double* out_dev, void* stream_handle);
+
+/* Per particle p, with s = anc[p] (anc NULL: s = p): eta0 = P0 + scale T0[s] (+ R0), eta1 = P1 + scale T1[s] (+ R1)
+ * (M <= 64, eta1 symmetric positive definite);
+ *   m[p] = eta0^T eta1^-1 phi[p],  c[p] = phi[p]^T eta1^-1 phi[p],  q[p] = eta0^T eta1^-1 eta0,  logdet[p] = log det eta1.
+ * R0/R1 (the reference trajectory's statistics, src/Algorithm3.py:96-101), phi and every output may be NULL.
+ * Returns PGAS_E_STATE if some eta1 was not positive definite. */
+int pgas_m_mniw_solve(pgas_ctx* ctx, int64_t n, int32_t M, double scale, const int32_t* anc_dev, const double* P0_dev, const double* P1_dev,
+                      const double* T0_dev, const double* T1_dev, const double* R0_dev, const double* R1_dev, const double* phi_dev,
+                      double* m_dev, double* c_dev, double* q_dev, double* logdet_dev, void* stream_handle);
+
+/* T_out[p] = scale * T_in[anc[p]] + (phi[p] xi[p], phi[p] phi[p]^T, xi[p]^2, 1); anc may be NULL (identity).  In and out must
+ * not alias. */
+int pgas_m_stats_gather_update(pgas_ctx* ctx, int64_t n, int32_t M, double scale, const int32_t* anc_dev, const double* T0_in,
+                               const double* T1_in, const double* T2_in, const double* T3_in, const double* phi_dev,
+                               const double* xi_dev, double* T0_out, double* T1_out, double* T2_out, double* T3_out,
+                               void* stream_handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGAS_MARGINAL_H */

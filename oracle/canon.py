@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libpgas_oracle.so")
 
 STREAM_INIT, STREAM_PROP, STREAM_RESAMPLE, STREAM_ANCESTOR, STREAM_FINAL = 1, 2, 3, 4, 5
+STREAM_M_INIT_STATE, STREAM_M_STATE, STREAM_M_RESAMPLE, STREAM_M_ANCESTOR, STREAM_M_FINAL, STREAM_M_INIT_INTVAR, STREAM_M_INTVAR = 16, 17, 18, 19, 20, 24, 32
 
 
 def build(force=False):
@@ -60,6 +61,10 @@ def lib():
         L.oc_uniform.restype = C.c_double
         L.oc_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.oc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int, dp]
+        L.oc_student_t.restype = None
+        L.oc_student_t.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, dp, dp]
+        L.oc_gamma.restype = None
+        L.oc_gamma.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, dp, dp]
         L.oc_u64_to_double.restype = C.c_double
         L.oc_u64_to_double.argtypes = [C.c_uint64]
         L.oc_segment_partials.argtypes = [dp, C.c_int64, dp, u64p, u64p]
@@ -119,6 +124,21 @@ def normals(seed, stream, t, p0, n_particles, n):
     z = np.empty((n_particles, n))
     lib().oc_normals(seed, stream, t, p0, n_particles, n, _dp(z))
     return z
+
+
+def student_t(seed, stream, t, p0, nu):
+    """Student-t(nu[p]) variates of particles p0.. (canonical Marsaglia-Tsang gamma sampler, include/pgas_canon.h)."""
+    nu = _f64(nu)
+    out = np.empty(nu.size)
+    lib().oc_student_t(seed, stream, t, p0, nu.size, _dp(nu), _dp(out))
+    return out
+
+
+def gamma(seed, stream, t, p0, a):
+    a = _f64(a)
+    out = np.empty(a.size)
+    lib().oc_gamma(seed, stream, t, p0, a.size, _dp(a), _dp(out))
+    return out
 
 
 def segment_partials(lw):

@@ -68,3 +68,34 @@ def index_mismatch_is_tie(a_canon, a_numpy, W_numpy, U, tol=1e-9):
         if not np.all(np.abs(W_numpy[lo:hi] - U[i]) < tol):
             return False
     return True
+
+
+class CanonRand:
+    """Random-number provider for oracle/marginal_numpy.py that reproduces the device's Philox streams (include/pgas_canon.h)
+    through the canonical C oracle: same (seed, stream, t, particle) addressing as pgas_amd.Algorithm1.DeviceRand."""
+
+    def __init__(self, seed, N):
+        self.seed, self.N = int(seed), int(N)
+
+    def normal(self, stream, t, ncol):
+        return canon.normals(self.seed, stream, t, 0, self.N, ncol)
+
+    def uniform(self, stream, t):
+        return canon.uniform(self.seed, stream, t)
+
+    def student_t(self, stream, t, nu, n=1):
+        assert n == 1
+        return canon.student_t(self.seed, stream, t, 0, np.broadcast_to(np.asarray(nu, dtype=np.float64), (self.N,)).copy()).reshape(self.N, 1)
+
+
+def marginal_oracle(problem, N, kind="Algorithm1"):
+    """NumPy restatement (oracle/marginal_numpy.py) of Algorithm1 / Algorithm3 for a pgas_amd.experiments.MarginalProblem."""
+    from oracle import marginal_numpy as mo
+
+    ssm = problem.ssm(mo.StateSpaceModel, np)
+    args = dict(N_samples=N, observations=problem.observations, inputs=problem.inputs, SSM=ssm, init_state_mean=problem.init_state_mean,
+                init_state_cov=problem.init_state_cov, init_int_var_mean=problem.init_int_var_mean, init_int_var_cov=problem.init_int_var_cov,
+                GP_prior=problem.GP_prior, basis_fcn=problem.basis_fcn())
+    if kind == "Algorithm1":
+        return mo.Algorithm1(forgetting_factor=problem.forgetting_factor, **args)
+    return mo.Algorithm3(**args)

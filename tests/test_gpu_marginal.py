@@ -1,0 +1,149 @@
+"""GPU tests of the marginalised family (pgas_amd.Algorithm1 / Algorithm3 / Algorithm2, include/pgas_marginal.h).
+
+Kernel numerics: each HIP kernel against a plain torch fp64 reference of the same operation (Cholesky-based quantities to
+1e-10 relative, the statistics update exactly), the random-number kernels bit for bit against the canonical C oracle.
+Algorithm parity: against the NumPy restatement of the reference (oracle/marginal_numpy.py) driven by the SAME Philox streams
+(common.CanonRand), tolerance 1e-8 relative on continuous outputs, ancestor indices equal."""
+import numpy as np
+import pytest
+import torch
+
+from common import CanonRand, canon, experiments, marginal_oracle, pgas_amd
+from oracle import marginal_numpy as mo
+
+pytestmark = pytest.mark.gpu
+SEED = 12345678
+
+
+def _ops(N):
+    from pgas_amd._lib import MarginalOps
+
+    return MarginalOps(N)
+
+
+def test_rng_kernels_bit_exact():
+    N = 5000
+    ops = _ops(N)
+    for ncol in (1, 2, 3):
+        z = ops.normal(SEED, 17, 9, ncol).cpu().numpy()
+        assert np.array_equal(z, canon.normals(SEED, 17, 9, 0, N, ncol))
+    nu = np.concatenate([np.full(1000, 1.0), np.full(1000, 3.0), np.linspace(2.0, 2000.0, 3000)])
+    t = ops.student_t(SEED, 32, 4, torch.as_tensor(nu)).cpu().numpy()
+    assert np.array_equal(t, canon.student_t(SEED, 32, 4, 0, nu))
+    assert ops.uniform(SEED, 18, 7) == canon.uniform(SEED, 18, 7)
+
+
+@pytest.mark.parametrize("N,M", [(300, 41), (1000, 20), (257, 64), (64, 1)])
+def test_mniw_solve_against_torch(N, M):
+    ops = _ops(N)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    dev = ops.device
+    B = torch.randn(N, M, 3, generator=g, dtype=torch.float64)
+    T1 = (B @ B.transpose(1, 2)).to(dev).contiguous()
+    T0 = torch.randn(N, M, generator=g, dtype=torch.float64).to(dev)
+    P1 = torch.diag(torch.rand(M, generator=g, dtype=torch.float64) + 0.5).to(dev)
+    P0 = torch.randn(M, generator=g, dtype=torch.float64).to(dev)
+    phi = torch.randn(N, M, generator=g, dtype=torch.float64).to(dev)
+    anc = torch.randint(0, N, (N,), generator=g).to(dev).to(torch.int32)
+    R1 = (torch.randn(M, M, generator=g, dtype=torch.float64) * 0.1).to(dev)
+    R1 = (R1 @ R1.T).contiguous()
+    R0 = torch.randn(M, generator=g, dtype=torch.float64).to(dev)
+    for scale, a, r0, r1 in ((1.0, None, None, None), (0.999, anc, None, None), (1.0, None, R0, R1)):
+        sol = ops.mniw_solve(P0, P1, T0, T1, scale=scale, anc=a, R0=r0, R1=r1, phi=phi)
+        idx = torch.arange(N, device=dev) if a is None else a.long()
+        eta1 = P1 + scale * T1[idx] + (0 if r1 is None else r1)
+        eta0 = (P0 + scale * T0[idx] + (0 if r0 is None else r0)).unsqueeze(-1)
+        L = torch.linalg.cholesky(eta1)
+        v = torch.linalg.solve_triangular(L, phi.unsqueeze(-1), upper=False)
+        w = torch.linalg.solve_triangular(L, eta0, upper=False)
+        ref = {"m": (w * v).sum((1, 2)), "c": (v * v).sum((1, 2)), "q": (w * w).sum((1, 2)), "logdet": 2 * torch.log(torch.diagonal(L, dim1=1, dim2=2)).sum(1)}
+        for k in ref:
+            err = (sol[k] - ref[k]).abs().max().item() / max(1.0, ref[k].abs().max().item())
+            assert err < 1e-10, (k, err)
+    # a matrix that is not positive definite is reported, not silently processed
+    bad = T1.clone()
+    bad[5] = -torch.eye(M, dtype=torch.float64, device=dev) * 10
+    with pytest.raises(Exception, match="positive definite"):
+        ops.mniw_solve(P0, P1, T0, bad, phi=phi)
+
+
+def test_stats_gather_update_exact():
+    N, M = 700, 41
+    ops = _ops(N)
+    dev = ops.device
+    g = torch.Generator(device="cpu").manual_seed(4)
+    T = (torch.randn(N, M, generator=g, dtype=torch.float64).to(dev), torch.randn(N, M, M, generator=g, dtype=torch.float64).to(dev),
+         torch.rand(N, generator=g, dtype=torch.float64).to(dev), torch.rand(N, generator=g, dtype=torch.float64).to(dev) * 10)
+    phi = torch.randn(N, M, generator=g, dtype=torch.float64).to(dev)
+    xi = torch.randn(N, generator=g, dtype=torch.float64).to(dev)
+    anc = torch.sort(torch.randint(0, N, (N,), generator=g)).values.to(dev).to(torch.int32)
+    for lam, a in ((0.999, anc), (1.0, None)):
+        out = ops.stats_gather_update(lam, a, T, phi, xi)
+        idx = torch.arange(N, device=dev) if a is None else a.long()
+        ref = (lam * T[0][idx] + phi * xi[:, None], lam * T[1][idx] + phi[:, :, None] * phi[:, None, :], lam * T[2][idx] + xi * xi, lam * T[3][idx] + 1.0)
+        for o_, r_ in zip(out, ref):
+            assert torch.equal(o_, r_)
+
+
+def _device_alg(pb, N, kind="Algorithm1"):
+    ssm = pb.ssm(pgas_amd.StateSpaceModel, torch)
+    args = dict(N_samples=N, observations=pb.observations, inputs=pb.inputs, SSM=ssm, init_state_mean=pb.init_state_mean,
+                init_state_cov=pb.init_state_cov, init_int_var_mean=pb.init_int_var_mean, init_int_var_cov=pb.init_int_var_cov,
+                GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn())
+    if kind == "Algorithm1":
+        return pgas_amd.Algorithm1(forgetting_factor=pb.forgetting_factor, **args)
+    return pgas_amd.Algorithm3(**args)
+
+
+def _close(gpu, ref, what, tol=1e-8):
+    g = gpu.cpu().numpy().reshape(np.shape(ref))
+    err = np.abs(g - ref).max() / max(1.0, np.abs(ref).max())
+    assert err < tol, f"{what}: relative error {err:.3e}"
+
+
+@pytest.mark.parametrize("name,N", [("smo", 200), ("toy", 200), ("smo", 1500)])
+def test_algorithm1_matches_restatement(name, N):
+    pb = experiments.smo_marginal(T=8) if name == "smo" else experiments.toy_marginal(T=8)
+    ref = marginal_oracle(pb, N)(CanonRand(SEED, N))
+    got = _device_alg(pb, N)(SEED)
+    assert np.array_equal(got[4].cpu().numpy(), ref[4]), "ancestor_trace"
+    _close(got[0], ref[0], "state_trace")
+    _close(got[1][0], ref[1][0], "int_var_trace")
+    for j in range(4):
+        _close(got[2][0][j], ref[2][0][j], f"suff_stats_trace[{j}]")
+        _close(got[5][0][j], ref[5][0][j], f"suff_stats[{j}]")
+    _close(got[3], ref[3], "weights_trace")
+    _close(got[6], ref[6], "obs_trace")
+    _close(got[7], ref[7], "log_likelihood", tol=1e-7)
+    assert got[2][0][0].shape == (pb.T, pb.GP_prior[0][0].shape[0], 1) and got[5][0][2].shape == (N, 1, 1)   # the reference's shapes
+
+
+@pytest.mark.parametrize("name,N", [("smo", 150), ("toy", 150)])
+def test_algorithm3_matches_restatement(name, N):
+    pb = experiments.smo_marginal(T=8) if name == "smo" else experiments.toy_marginal(T=8)
+    oracle = marginal_oracle(pb, N, "Algorithm3")
+    ref_x, ref_iv = pb.X_true, [pb.int_var_true[0]]
+    ref_stats = mo.trajectory_stats(oracle, ref_x, ref_iv)
+    traj, ivt, tr = oracle(CanonRand(SEED, N), ref_x, ref_iv, ref_stats)
+    alg = _device_alg(pb, N, "Algorithm3")
+    gt, gi, gtr = alg(SEED, ref_x, ref_iv, ref_stats, return_traces=True)
+    assert np.array_equal(gtr["ancestor_trace"].cpu().numpy(), tr["ancestor_trace"]) and gtr["idx"] == tr["idx"]
+    _close(gtr["state_trace"], tr["state_trace"], "state_trace")
+    _close(gtr["log_weights"], tr["log_weights"], "final log-weights", tol=1e-7)
+    _close(gt, traj, "state trajectory")
+    _close(gi[0], ivt[0], "interface-variable trajectory")
+
+
+def test_algorithm2_runs_and_returns_reference_shapes():
+    pb = experiments.toy_marginal(T=12)
+    N, K = 64, 4
+    ssm = pb.ssm(pgas_amd.StateSpaceModel, torch)
+    alg = pgas_amd.Algorithm2(N_samples=N, N_iterations=K, observations=pb.observations, inputs=pb.inputs, SSM=ssm, init_state_mean=pb.init_state_mean,
+                              init_state_cov=pb.init_state_cov, init_int_var_mean=pb.init_int_var_mean, init_int_var_cov=pb.init_int_var_cov,
+                              GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn())
+    X, IV, W, SS, OBS, LL = alg(SEED, pb.X_true, [pb.int_var_true[0]])
+    T = pb.T
+    assert X.shape == (T, K, 1) and IV[0].shape == (T, K, 1) and W.shape == (T, K) and OBS.shape == (T, K, 1) and LL.shape == (T, K)
+    assert SS[0][0].shape == (K, 40, 1) and SS[0][1].shape == (K, 40, 40) and SS[0][3].shape == (K,)
+    assert torch.isfinite(X).all() and torch.isfinite(LL).all() and torch.all(SS[0][3] == T)
+    assert torch.allclose(X[:, 0, 0], torch.as_tensor(pb.X_true[:, 0], device=X.device))
