@@ -87,7 +87,7 @@ class Algorithm1:
 
     def _weighted(self, stats, w):
         """sum_n w_n T_n for the statistics trace (src/Algorithm1.py:166-170, :445-457)."""
-        return (w @ stats[0], (w @ stats[1].reshape(w.shape[0], -1)).reshape(stats[1].shape[1:]), w @ stats[2], w @ stats[3])
+        return self.ops.weighted_stats(w, stats)
 
     # ------------------------------------------------------------------------------------------------------ :100-177
     def _init_trace_vars(self):
@@ -184,6 +184,7 @@ class Algorithm1:
                 int_var_trace[i][time] = iv[i]
                 for j, v in enumerate(self._weighted(suff_stats[i], w)):
                     sst[i][j][time] = v.reshape(sst[i][j][time].shape)                     # :445-457
+        self.ops.check()
         weights_trace = torch.softmax(lw_trace, dim=1)                                     # :460
         obs_trace = torch.stack([self.SSM.output_mdl(state_trace[t], self.inputs[t], *[v[t] for v in int_var_trace]).reshape(self.N_samples, -1)
                                  for t in range(T)])                                       # :463-468
@@ -235,14 +236,16 @@ class Algorithm3(Algorithm1):
             g = torch.zeros(N, dtype=torch.float64, device=dev)
             for i in range(self.N_int):                                                    # :93-108  g_t - g_T
                 g = g + self._log_base_measure(i, suff_stats[i]) - self._log_base_measure(i, suff_stats[i], ref_suff_stats[i])
-            Q = self.SSM.process_noise
-            Lq = np.linalg.cholesky(Q)
-            e = (ref_state.reshape(1, -1) - aux_state) @ _t(np.linalg.inv(Lq), dev).T      # :109-116
-            h_x = -0.5 * Q.shape[0] * math.log(2 * math.pi) - float(np.sum(np.log(np.diag(Lq)))) - 0.5 * (e * e).sum(dim=1)
+            if getattr(self, "_Qc", None) is None:
+                Lq = np.linalg.cholesky(self.SSM.process_noise)
+                self._Qc = (_t(np.linalg.inv(Lq), dev).T.contiguous(), -0.5 * Lq.shape[0] * math.log(2 * math.pi) - float(np.sum(np.log(np.diag(Lq)))))
+            e = (ref_state.reshape(1, -1) - aux_state) @ self._Qc[0]                       # :109-116
+            h_x = self._Qc[1] - 0.5 * (e * e).sum(dim=1)
             w_anc = torch.softmax(lw_aux + g + h_x, dim=0)                                 # :117-118
-            ref_idx = int(torch.searchsorted(torch.cumsum(w_anc, 0), torch.tensor([rand.uniform(STREAM_ANCESTOR, time)], dtype=torch.float64, device=dev))[0])
+            u = torch.full((1,), rand.uniform(STREAM_ANCESTOR, time), dtype=torch.float64, device=dev)
+            ref_idx = torch.clamp(torch.searchsorted(torch.cumsum(w_anc, 0), u)[0], max=N - 1)     # stays on the device: no host round trip
         a = a.clone()
-        a[-1] = min(ref_idx, N - 1)                                                        # :121-127 (clip: SURVEY Q4)
+        a[-1] = ref_idx                                                                    # :121-127 (clip: SURVEY Q4)
         new_state = self._draw_states(rand, time, state, int_var, a)                       # :130-133
         new_state[-1] = ref_state                                                          # :134
         new_int_var, new_basis = self._draw_int_vars(rand, time, new_state, suff_stats, a)                       # :139-148
@@ -286,6 +289,7 @@ class Algorithm3(Algorithm1):
             state_trace[time], lw_trace[time], anc_trace[time - 1] = x, lw, a
             for i in range(self.N_int):
                 int_var_trace[i][time] = iv[i]
+        self.ops.check()
         w = torch.softmax(lw_trace[-1], dim=0)                                             # :293
         u = torch.tensor([rand.uniform(STREAM_FINAL, 0)], dtype=torch.float64, device=dev)
         idx = min(int(torch.searchsorted(torch.cumsum(w, 0), u)[0]), self.N_samples - 1)   # :294

@@ -38,7 +38,7 @@ EXPORTS = [
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
-    "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_mniw_solve", "pgas_m_stats_gather_update",
+    "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_mniw_solve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
 ]
 
 _lib = None
@@ -109,6 +109,10 @@ def load():
     L.pgas_m_rng_student_t.argtypes = [vp, u64, u32, u32, i64, i64, vp, vp, vp]
     L.pgas_m_mniw_solve.restype = C.c_int
     L.pgas_m_mniw_solve.argtypes = [vp, i64, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_weighted_stats.restype = C.c_int
+    L.pgas_m_weighted_stats.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_check.restype = C.c_int
+    L.pgas_m_check.argtypes = [vp, vp]
     L.pgas_m_stats_gather_update.restype = C.c_int
     L.pgas_m_stats_gather_update.argtypes = [vp, i64, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     _lib = L
@@ -400,12 +404,16 @@ class MarginalOps:
         for arr in (P0, P1, T0, T1, R0, R1, phi):
             if arr is not None and not (arr.is_contiguous() and arr.dtype == torch.float64 and arr.device == self.device):
                 raise ValueError("mniw_solve: operands must be contiguous fp64 tensors on the engine's device")
-        if a is not None and (a.numel() != n or int(a.min()) < 0 or int(a.max()) >= n):
-            raise ValueError("mniw_solve: ancestor indices out of range")
+        if a is not None and a.numel() != n:
+            raise ValueError("mniw_solve: one ancestor index per particle expected")
         self.eng._chk(self.lib.pgas_m_mniw_solve(self.eng._h, n, M, float(scale), self._ptr(a), P0.data_ptr(), P1.data_ptr(), T0.data_ptr(), T1.data_ptr(),
                                                  self._ptr(R0), self._ptr(R1), self._ptr(phi), self._ptr(out.get("m")), self._ptr(out.get("c")),
                                                  self._ptr(out.get("q")), self._ptr(out.get("logdet")), self.eng._stream()), "pgas_m_mniw_solve")
         return out
+
+    def check(self):
+        """Synchronises; raises if a matrix handed to mniw_solve since the last check was not positive definite."""
+        self.eng._chk(self.lib.pgas_m_check(self.eng._h, self.eng._stream()), "pgas_m_check")
 
     def stats_gather_update(self, scale, anc, T, phi, xi):
         """T = (T0 (n,M), T1 (n,M,M), T2 (n,), T3 (n,)) -> scale * T[anc] + statistics of (xi, phi); new tensors."""
@@ -413,8 +421,8 @@ class MarginalOps:
         n, M = T0.shape
         out = (torch.empty_like(T0), torch.empty_like(T1), torch.empty_like(T2), torch.empty_like(T3))
         a = None if anc is None else anc.to(device=self.device, dtype=torch.int32).contiguous()
-        if a is not None and (a.numel() != n or int(a.min()) < 0 or int(a.max()) >= n):
-            raise ValueError("stats_gather_update: ancestor indices out of range")
+        if a is not None and a.numel() != n:
+            raise ValueError("stats_gather_update: one ancestor index per particle expected")
         if phi.shape != (n, M) or xi.numel() != n or T1.shape != (n, M, M):
             raise ValueError("stats_gather_update: operand shapes do not match (n, M)")
         self.eng._chk(self.lib.pgas_m_stats_gather_update(self.eng._h, n, M, float(scale), self._ptr(a), T0.data_ptr(), T1.data_ptr(), T2.data_ptr(),
@@ -422,6 +430,18 @@ class MarginalOps:
                                                           out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), self.eng._stream()),
                       "pgas_m_stats_gather_update")
         return out
+
+    def weighted_stats(self, w, T):
+        """sum_p w[p] T[p] for T = (T0 (n,M), T1 (n,M,M), T2 (n,), T3 (n,)) -> (S0 (M,), S1 (M,M), S2 (), S3 ())."""
+        T0, T1, T2, T3 = T
+        n, M = T0.shape
+        w = w.contiguous()
+        S0, S1 = torch.empty(M, dtype=torch.float64, device=self.device), torch.empty((M, M), dtype=torch.float64, device=self.device)
+        S23 = torch.empty(2, dtype=torch.float64, device=self.device)
+        self.eng._chk(self.lib.pgas_m_weighted_stats(self.eng._h, n, M, w.data_ptr(), T0.data_ptr(), T1.data_ptr(), T2.data_ptr(), T3.data_ptr(),
+                                                     S0.data_ptr(), S1.data_ptr(), S23.data_ptr(), S23.data_ptr() + 8, self.eng._stream()),
+                      "pgas_m_weighted_stats")
+        return S0, S1, S23[0], S23[1]
 
     def systematic_resample(self, u, logw):
         return self.eng.systematic_resample(u, logw)

@@ -74,6 +74,8 @@ struct pgas_ctx {
     int corrected = 0;          // PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE: propagate from the resampled ancestors (quirk Q1 removed)
     double* aux_buf = nullptr;  // (N, nx) transition means of the current step, corrected mode only
     int32_t* d_fail = nullptr;  // failure counter of pgas_m_mniw_solve
+    double* ws_partial = nullptr;  // per-chunk partial sums of pgas_m_weighted_stats
+    size_t ws_bytes = 0;
     init_fn init = nullptr;
     basis_fn basis = nullptr;
     // device tables
@@ -286,7 +288,7 @@ void pgas_destroy(pgas_ctx* c) {
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
     hipFree(c->segm_g[0]); hipFree(c->segm_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
-    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail);
+    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail); hipFree(c->ws_partial);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (hipEvent_t e : c->evp) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
@@ -886,18 +888,28 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
     if (n == 0) return PGAS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)sh;
-    if (!c->d_fail) HIPCHK(c, hipMalloc(&c->d_fail, sizeof(int32_t)));
-    HIPCHK(c, hipMemsetAsync(c->d_fail, 0, sizeof(int32_t), st));
-    const size_t per = (size_t)M * (M | 1) * sizeof(double);
-    int waves = (int)((60 * 1024) / per);
-    waves = waves > 4 ? 4 : waves < 1 ? 1 : waves;
-    hipLaunchKernelGGL(k_mniw_solve, dim3((unsigned)((n + waves - 1) / waves)), dim3(64 * waves), waves * per, st, n, M, scale, anc, P0, P1, T0, T1, R0, R1,
-                       phi, m, cc, q, logdet, c->d_fail);
+    if (!c->d_fail) {
+        HIPCHK(c, hipMalloc(&c->d_fail, sizeof(int32_t)));
+        HIPCHK(c, hipMemsetAsync(c->d_fail, 0, sizeof(int32_t), st));
+    }
+    const int waves = 4;
+    const dim3 grd((unsigned)((n + waves - 1) / waves)), blk(64 * waves);
+    auto kern = M <= 24 ? k_mniw_solve<24> : M <= 32 ? k_mniw_solve<32> : M <= 42 ? k_mniw_solve<42> : M <= 48 ? k_mniw_solve<48> : k_mniw_solve<64>;
+    hipLaunchKernelGGL(kern, grd, blk, (size_t)waves * (M * (M + 1) / 2) * sizeof(double), st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q, logdet, c->d_fail);
     KCHK(c, "k_mniw_solve");
+    return PGAS_OK;
+}
+
+int pgas_m_check(pgas_ctx* c, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->d_fail) return PGAS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)sh;
     int32_t bad = 0;
     HIPCHK(c, hipMemcpyAsync(&bad, c->d_fail, sizeof bad, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipMemsetAsync(c->d_fail, 0, sizeof(int32_t), st));
     HIPCHK(c, hipStreamSynchronize(st));
-    if (bad) FAIL(c, PGAS_E_STATE, "pgas_m_mniw_solve: %d of %lld matrices eta1 are not positive definite", bad, (long long)n);
+    if (bad) FAIL(c, PGAS_E_STATE, "pgas_m_mniw_solve: %d matrices eta1 were not positive definite since the last check", bad);
     return PGAS_OK;
 }
 
@@ -912,5 +924,31 @@ int pgas_m_stats_gather_update(pgas_ctx* c, int64_t n, int32_t M, double scale, 
     HIPCHK(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_stats_gather_update, dim3((unsigned)n), dim3(256), 0, (hipStream_t)sh, n, M, scale, anc, T0i, T1i, T2i, T3i, phi, xi, T0o, T1o, T2o, T3o);
     KCHK(c, "k_stats_gather_update");
+    return PGAS_OK;
+}
+
+int pgas_m_weighted_stats(pgas_ctx* c, int64_t n, int32_t M, const double* w, const double* T0, const double* T1, const double* T2, const double* T3,
+                          double* S0, double* S1, double* S2, double* S3, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!w || !T0 || !T1 || !T2 || !T3 || !S0 || !S1 || !S2 || !S3 || n < 1) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: bad argument");
+    if (M < 1 || M > 2 * PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: M = %d outside [1, %d]", M, 2 * PG_MN_MAXM);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)sh;
+    const int ncol = M * M + M + 2;
+    const int64_t nchunk = (n + PG_WS_CHUNK - 1) / PG_WS_CHUNK;
+    if (nchunk > 65535) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: n = %lld too large", (long long)n);
+    const size_t need = (size_t)nchunk * ncol * sizeof(double);
+    if (c->ws_bytes < need) {
+        HIPCHK(c, hipStreamSynchronize(st));
+        hipFree(c->ws_partial);
+        c->ws_partial = nullptr;
+        c->ws_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->ws_partial, need));
+        c->ws_bytes = need;
+    }
+    hipLaunchKernelGGL(k_weighted_stats_partial, dim3((ncol + 255) / 256, (unsigned)nchunk), dim3(256), 0, st, n, M, w, T0, T1, T2, T3, c->ws_partial);
+    KCHK(c, "k_weighted_stats_partial");
+    hipLaunchKernelGGL(k_weighted_stats_final, dim3((ncol + 255) / 256), dim3(256), 0, st, (int)nchunk, M, c->ws_partial, S0, S1, S2, S3);
+    KCHK(c, "k_weighted_stats_final");
     return PGAS_OK;
 }

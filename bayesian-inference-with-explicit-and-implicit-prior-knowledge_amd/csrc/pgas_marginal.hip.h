@@ -37,77 +37,100 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// Dynamic LDS: blockDim.x / 64 matrices of M x LD doubles, LD = M | 1 (odd stride: column reads hit distinct banks).
+// One wave per particle, lane = matrix row, the row held in registers (MT = compile-time row capacity; rows/columns beyond M are
+// padded with the identity, which changes neither the solves nor the determinant).  Right-looking Cholesky with every loop unrolled: column k of L is broadcast lane by
+// lane with v_readlane (wave-uniform indices), so the trailing update is one FMA and two readlanes per matrix element; the
+// forward substitutions of both right-hand sides ride along column by column.  1/sqrt(pivot) comes from v_rsq_f64 plus two
+// Newton steps (relative error ~1e-16) instead of an IEEE sqrt and an IEEE division: that chain of ~60 dependent instructions
+// per column was the critical path of the whole kernel.
+__device__ __forceinline__ double rsqrt_newton(double a) {
+    double y = __builtin_amdgcn_rsq(a);
+    const double h = 0.5 * a;
+    y = y * PGAS_FMA(-h * y, y, 1.5);
+    y = y * PGAS_FMA(-h * y, y, 1.5);
+    return y;
+}
+template <int MT>
 __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double scale, const int32_t* __restrict__ anc, const double* __restrict__ P0,
-                                                                   const double* __restrict__ P1, const double* __restrict__ T0,
-                                                                   const double* __restrict__ T1, const double* __restrict__ R0,
-                                                                   const double* __restrict__ R1, const double* __restrict__ phi,
-                                                                   double* __restrict__ m_out, double* __restrict__ c_out,
-                                                                   double* __restrict__ q_out, double* __restrict__ logdet_out,
-                                                                   int32_t* __restrict__ fail_out) {
+                                                     const double* __restrict__ P1, const double* __restrict__ T0,
+                                                     const double* __restrict__ T1, const double* __restrict__ R0,
+                                                     const double* __restrict__ R1, const double* __restrict__ phi,
+                                                     double* __restrict__ m_out, double* __restrict__ c_out,
+                                                     double* __restrict__ q_out, double* __restrict__ logdet_out,
+                                                     int32_t* __restrict__ fail_out) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (p >= n) return;  // whole wave leaves together; no workgroup barrier below
-    const int LD = M | 1;
-    double* __restrict__ A = smem + (size_t)wave * M * LD;
-    // eta1 = P1 + scale * T1_p (+ R1): coalesced over the flattened matrix
     const int64_t src = anc ? (int64_t)anc[p] : p;   // statistics of the resampled ancestor (src/Algorithm1.py:358-361)
+    // Only the lower triangle is needed (lane l uses columns <= l).  Row r is read by lanes 0..r, contiguous in memory, and parked
+    // in LDS in packed triangular order; then every lane picks up its own row.  Half the matrix never leaves HBM.
+    const int tri_n = M * (M + 1) / 2;
+    double* __restrict__ A = smem + (size_t)wave * tri_n;
     const double* __restrict__ T1p = T1 + (size_t)src * M * M;
-    for (int e = lane; e < M * M; e += 64) {
-        const int r = e / M, cc = e - r * M;
-        double v = P1[e] + scale * T1p[e];
-        if (R1) v += R1[e];
-        A[r * LD + cc] = v;
+#pragma unroll 6
+    for (int r = 0; r < M; ++r) {
+        if (lane <= r) {
+            double v = P1[r * M + lane] + scale * T1p[r * M + lane];
+            if (R1) v += R1[r * M + lane];
+            A[r * (r + 1) / 2 + lane] = v;
+        }
     }
-    // right-hand sides: lane l holds b_l = phi_l and w_l = eta0_l
-    double b = 0.0, w = 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int tl = lane < M ? lane * (lane + 1) / 2 : 0;
+    double row[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const bool have = lane < M && j <= lane;   // j <= lane < M
+        const double v = A[have ? tl + j : 0];
+        row[j] = have ? v : (j == lane ? 1.0 : 0.0);
+    }
+    double b = 0.0, w = 0.0;  // right-hand sides: lane l holds phi_l and eta0_l
     if (lane < M) {
         w = P0[lane] + scale * T0[(size_t)src * M + lane];
         if (R0) w += R0[lane];
         if (phi) b = phi[(size_t)p * M + lane];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // right-looking Cholesky, lane = row; the forward substitutions ride along column by column
-    double logdet = 0.0;
+    double diag = 1.0;  // pivot of this lane's column (before the square root)
     int bad = 0;
-    for (int k = 0; k < M; ++k) {
-        const double akk = A[k * LD + k];
+#pragma unroll
+    for (int k = 0; k < MT; ++k) {
+        const double akk = readlane_f64(row[k], k);
         if (!(akk > 0.0)) bad = 1;
-        const double d = sqrt(akk);
-        logdet += pgas_log(akk);  // log det = sum log L_kk^2
-        double lk = 0.0;          // L[lane][k]
-        if (lane > k && lane < M) {
-            lk = A[lane * LD + k] / d;
-            A[lane * LD + k] = lk;
-        }
-        // forward substitution step k for both right-hand sides
-        const double bk = __shfl(b, k) / d, wk = __shfl(w, k) / d;
+        const double inv = rsqrt_newton(akk);
+        const double lk = row[k] * inv;  // L[lane][k] for lane > k (lanes <= k carry values nobody reads)
+        if (lane == k) diag = akk;
+        const double bk = readlane_f64(b, k) * inv, wk = readlane_f64(w, k) * inv;
         if (lane == k) {
             b = bk;
             w = wk;
         } else if (lane > k) {
-            b -= lk * bk;
-            w -= lk * wk;
+            b = PGAS_FMA(-lk, bk, b);
+            w = PGAS_FMA(-lk, wk, w);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // trailing update of row `lane`: A[lane][j] -= L[lane][k] L[j][k], k < j <= lane
-        if (lane > k && lane < M) {
-            for (int j = k + 1; j <= lane; ++j) A[lane * LD + j] -= lk * A[j * LD + k];
+        // A[lane][j] -= L[lane][k] L[j][k] (only lanes >= j are read later); in groups of 8 so the broadcast values stay in SGPRs
+        const double nlk = -lk;
+#pragma unroll
+        for (int j0 = k + 1; j0 < MT; j0 += 8) {
+#pragma unroll
+            for (int j = j0; j < j0 + 8 && j < MT; ++j) {
+                row[j] = PGAS_FMA(nlk, readlane_f64(lk, j), row[j]);
+                asm volatile("" : "+v"(row[j]));  // consume the broadcast here: otherwise the compiler defers all updates of column j
+                                                  // to iteration j and keeps (spills) every broadcast value until then
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
     }
     const double mm = wave_sum_f64(lane < M ? w * b : 0.0);
     const double cc = wave_sum_f64(lane < M ? b * b : 0.0);
     const double qq = wave_sum_f64(lane < M ? w * w : 0.0);
+    const double ld = wave_sum_f64(lane < M ? pgas_log(diag) : 0.0);  // log det = sum log L_kk^2
     if (lane == 0) {
         if (m_out) m_out[p] = mm;
         if (c_out) c_out[p] = cc;
         if (q_out) q_out[p] = qq;
-        if (logdet_out) logdet_out[p] = logdet;
+        if (logdet_out) logdet_out[p] = ld;
         if (bad && fail_out) atomicAdd(fail_out, 1);
     }
 }
@@ -140,4 +163,49 @@ __global__ __launch_bounds__(256) void k_stats_gather_update(int64_t n, int M, d
         T2o[p] = scale * T2i[a] + x * x;
         T3o[p] = scale * T3i[a] + 1.0;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Weighted reduction over the particle axis (src/Algorithm1.py:166-170, :445-457):
+//   S = sum_p w_p (T0_p, T1_p, T2_p, T3_p)
+// a (1 x n) by (n x (M^2 + M + 2)) contraction that is pure streaming: every statistic is read exactly once.
+// Thread = one column of the concatenated record [T1 | T0 | T2 | T3], workgroup = 256 columns x one chunk of particles;
+// partial sums per chunk, then a second pass adds the chunks in index order (deterministic, no atomics).
+// ------------------------------------------------------------------------------------------
+#define PG_WS_CHUNK 512
+__device__ __forceinline__ double ws_column(int col, int M, int64_t p, const double* __restrict__ T0, const double* __restrict__ T1,
+                                            const double* __restrict__ T2, const double* __restrict__ T3) {
+    const int mm = M * M;
+    if (col < mm) return T1[(size_t)p * mm + col];
+    if (col < mm + M) return T0[(size_t)p * M + (col - mm)];
+    return col == mm + M ? T2[p] : T3[p];
+}
+__global__ __launch_bounds__(256) void k_weighted_stats_partial(int64_t n, int M, const double* __restrict__ w, const double* __restrict__ T0,
+                                                                 const double* __restrict__ T1, const double* __restrict__ T2,
+                                                                 const double* __restrict__ T3, double* __restrict__ partial) {
+    const int ncol = M * M + M + 2;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.y * PG_WS_CHUNK;
+    const int64_t p1 = p0 + PG_WS_CHUNK < n ? p0 + PG_WS_CHUNK : n;
+    if (col >= ncol) return;
+    double acc0 = 0.0, acc1 = 0.0;  // two chains: the loads of consecutive particles overlap
+    int64_t p = p0;
+    for (; p + 1 < p1; p += 2) {
+        acc0 = PGAS_FMA(w[p], ws_column(col, M, p, T0, T1, T2, T3), acc0);
+        acc1 = PGAS_FMA(w[p + 1], ws_column(col, M, p + 1, T0, T1, T2, T3), acc1);
+    }
+    if (p < p1) acc0 = PGAS_FMA(w[p], ws_column(col, M, p, T0, T1, T2, T3), acc0);
+    partial[(size_t)blockIdx.y * ncol + col] = acc0 + acc1;
+}
+__global__ __launch_bounds__(256) void k_weighted_stats_final(int nchunk, int M, const double* __restrict__ partial, double* __restrict__ S0,
+                                                               double* __restrict__ S1, double* __restrict__ S2, double* __restrict__ S3) {
+    const int ncol = M * M + M + 2, mm = M * M;
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= ncol) return;
+    double acc = 0.0;
+    for (int c = 0; c < nchunk; ++c) acc += partial[(size_t)c * ncol + col];
+    if (col < mm) S1[col] = acc;
+    else if (col < mm + M) S0[col - mm] = acc;
+    else if (col == mm + M) S2[0] = acc;
+    else S3[0] = acc;
 }

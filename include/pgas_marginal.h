@@ -35,10 +35,14 @@ int pgas_m_rng_student_t(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t
  * (M <= 64, eta1 symmetric positive definite);
  *   m[p] = eta0^T eta1^-1 phi[p],  c[p] = phi[p]^T eta1^-1 phi[p],  q[p] = eta0^T eta1^-1 eta0,  logdet[p] = log det eta1.
  * R0/R1 (the reference trajectory's statistics, src/Algorithm3.py:96-101), phi and every output may be NULL.
- * Returns PGAS_E_STATE if some eta1 was not positive definite. */
+ * Asynchronous; a matrix that is not positive definite is counted on the device and reported by pgas_m_check. */
 int pgas_m_mniw_solve(pgas_ctx* ctx, int64_t n, int32_t M, double scale, const int32_t* anc_dev, const double* P0_dev, const double* P1_dev,
                       const double* T0_dev, const double* T1_dev, const double* R0_dev, const double* R1_dev, const double* phi_dev,
                       double* m_dev, double* c_dev, double* q_dev, double* logdet_dev, void* stream_handle);
+
+/* Synchronises the stream; PGAS_E_STATE if any pgas_m_mniw_solve since the last check met a matrix that was not positive
+ * definite (its outputs are NaN). */
+int pgas_m_check(pgas_ctx* ctx, void* stream_handle);
 
 /* T_out[p] = scale * T_in[anc[p]] + (phi[p] xi[p], phi[p] phi[p]^T, xi[p]^2, 1); anc may be NULL (identity).  In and out must
  * not alias. */
@@ -46,6 +50,12 @@ int pgas_m_stats_gather_update(pgas_ctx* ctx, int64_t n, int32_t M, double scale
                                const double* T1_in, const double* T2_in, const double* T3_in, const double* phi_dev,
                                const double* xi_dev, double* T0_out, double* T1_out, double* T2_out, double* T3_out,
                                void* stream_handle);
+
+/* S = sum_p w[p] (T0[p], T1[p], T2[p], T3[p]): the weighted statistics trace of src/Algorithm1.py:166-170, :445-457
+ * (S0 (M), S1 (M,M), S2 (1), S3 (1)).  Streaming reduction in two deterministic passes. */
+int pgas_m_weighted_stats(pgas_ctx* ctx, int64_t n, int32_t M, const double* w_dev, const double* T0_dev, const double* T1_dev,
+                          const double* T2_dev, const double* T3_dev, double* S0_dev, double* S1_dev, double* S2_dev, double* S3_dev,
+                          void* stream_handle);
 
 #ifdef __cplusplus
 }

@@ -51,3 +51,22 @@ def test_emps_driver_fields_and_tracking():
     assert np.isfinite(res["offline_Sigma_X_PGAS"]).all()
     err = res["offline_Sigma_X_PGAS"][:, -1, 0] - res["X"][:, 0]
     assert np.sqrt(np.mean(err ** 2)) < 0.05
+
+
+def test_smo_driver_learns_the_spring_damper_force():
+    """examples/SingleMassOscillator_Simulation.py (BASELINE configs[0], shortened): the reference's .mat fields, and the online
+    estimate of the latent force F_sd = F_spring + F_damper is closer to the truth than the zero prior mean."""
+    drv = _driver("SingleMassOscillator_Simulation")
+    res = drv.run(particles=200, iterations=3, steps=400, log=lambda *_: None)
+    T, N, K = 400, 200, 3
+    assert res["online_Sigma_X"].shape == (T, N, 2) and res["online_Sigma_F"].shape == (T, N, 1) and res["online_weights"].shape == (T, N)
+    assert res["online_T0"].shape == (T, 41, 1) and res["online_T1"].shape == (T, 41, 41) and res["online_T3"].shape == (T,)
+    assert res["offline_Sigma_X"].shape == (T, K, 2) and res["offline_Sigma_F"].shape == (T, K, 1) and res["offline_T1"].shape == (K, 41, 41)
+    for k in ("online_Sigma_X", "online_Sigma_F", "offline_Sigma_X", "offline_log_likelihood"):
+        assert np.isfinite(res[k]).all(), k
+    # filtered position follows the simulated truth (measurement noise std 0.03)
+    xm = (res["online_Sigma_X"][:, :, 0] * res["online_weights"]).sum(axis=1)
+    assert np.sqrt(np.mean((xm[50:] - res["X"][50:, 0]) ** 2)) < 0.05
+    rmse, rms_true = drv.posterior_force_rmse(res, "online")
+    print("online F_sd RMSE", rmse, "RMS of the true force", rms_true)
+    assert rmse < 0.6 * rms_true

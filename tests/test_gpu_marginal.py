@@ -63,8 +63,11 @@ def test_mniw_solve_against_torch(N, M):
     # a matrix that is not positive definite is reported, not silently processed
     bad = T1.clone()
     bad[5] = -torch.eye(M, dtype=torch.float64, device=dev) * 10
+    ops.check()
+    ops.mniw_solve(P0, P1, T0, bad, phi=phi)
     with pytest.raises(Exception, match="positive definite"):
-        ops.mniw_solve(P0, P1, T0, bad, phi=phi)
+        ops.check()
+    ops.check()   # the counter is cleared by the failed check
 
 
 def test_stats_gather_update_exact():
@@ -83,6 +86,20 @@ def test_stats_gather_update_exact():
         ref = (lam * T[0][idx] + phi * xi[:, None], lam * T[1][idx] + phi[:, :, None] * phi[:, None, :], lam * T[2][idx] + xi * xi, lam * T[3][idx] + 1.0)
         for o_, r_ in zip(out, ref):
             assert torch.equal(o_, r_)
+
+
+@pytest.mark.parametrize("N,M", [(700, 41), (5000, 20), (513, 1)])
+def test_weighted_stats_against_torch(N, M):
+    ops = _ops(N)
+    dev = ops.device
+    g = torch.Generator(device="cpu").manual_seed(5)
+    T = (torch.randn(N, M, generator=g, dtype=torch.float64).to(dev), torch.randn(N, M, M, generator=g, dtype=torch.float64).to(dev),
+         torch.rand(N, generator=g, dtype=torch.float64).to(dev), torch.rand(N, generator=g, dtype=torch.float64).to(dev) * 10)
+    w = torch.softmax(torch.randn(N, generator=g, dtype=torch.float64), 0).to(dev)
+    S = ops.weighted_stats(w, T)
+    ref = (w @ T[0], (w @ T[1].reshape(N, -1)).reshape(M, M), w @ T[2], w @ T[3])
+    for s_, r_ in zip(S, ref):
+        assert (s_ - r_).abs().max().item() <= 1e-13 * max(1.0, r_.abs().max().item())
 
 
 def _device_alg(pb, N, kind="Algorithm1"):
