@@ -117,29 +117,33 @@ class Algorithm1:
 
     # ------------------------------------------------------------------------------------------------------ :179-232
     def _generate_auxiliary_states(self, state, time, int_var, suff_stats, scale=1.0):
+        """Returns (aux_state, aux_int_var, factors).  factors[i] keeps, per particle, the Cholesky factor of eta1 = prior + scale T1,
+        w = L^-1 eta0, q = w . w and log det eta1: the resampled children reuse them in _draw_int_vars (their matrix is their
+        ancestor's, :358-361) and Algorithm3 reads q / logdet for its base measures -- one factorisation per particle and step."""
         aux_state = self.SSM.transition_mdl(state, self.inputs[time - 1], *int_var)        # :206-208
-        aux_int_var = []
+        aux_int_var, factors = [], []
         for i in range(self.N_int):
             basis = self.basis_fcn[i](aux_state, self.inputs[time]).contiguous()           # :220-225
             P0, P1, _, _ = self.GP_prior[i]
             # mean_i phi = eta0^T eta1^-1 phi (BI:48-50, :228-231); `scale` carries the forgetting factor of :317-320
-            m = self.ops.mniw_solve(P0, P1, suff_stats[i][0], suff_stats[i][1], scale=scale, phi=basis, want=("m",))["m"]
-            aux_int_var.append(m.unsqueeze(-1))
-        return aux_state, tuple(aux_int_var)
+            sol = self.ops.mniw_solve(P0, P1, suff_stats[i][0], suff_stats[i][1], scale=scale, phi=basis, want=("m", "q", "logdet"), keep_factor=True)
+            aux_int_var.append(sol["m"].unsqueeze(-1))
+            factors.append(sol)
+        return aux_state, tuple(aux_int_var), factors
 
     # ------------------------------------------------------------------------------------------------------ :234-273
-    def _draw_int_vars(self, rand, time, state, suff_stats, a, scale=1.0):
-        """Interface variables drawn from the matrix-t predictive of the RESAMPLED statistics suff_stats[.][a]; the gather is folded
-        into the kernel (`anc`).  Returns (int_var, basis)."""
+    def _draw_int_vars(self, rand, time, state, suff_stats, a, factors, scale=1.0):
+        """Interface variables drawn from the matrix-t predictive of the RESAMPLED statistics suff_stats[.][a] (:251-262): a triangular
+        solve against the ancestor's stored factor.  Returns (int_var, basis)."""
         int_var, basis_all = [], []
+        ai = a.long()
         for i in range(self.N_int):
             basis = self.basis_fcn[i](state, self.inputs[time]).contiguous()               # :243-248
-            P0, P1, P2, P3 = self.GP_prior[i]
-            T0, T1, T2, T3 = suff_stats[i]
-            sol = self.ops.mniw_solve(P0, P1, T0, T1, scale=scale, anc=a, phi=basis, want=("m", "c", "q"))    # :251-262
-            ai = a.long()
+            _, _, P2, P3 = self.GP_prior[i]
+            _, _, T2, T3 = suff_stats[i]
+            sol = self.ops.mniw_trisolve(factors[i], a, basis)                             # m = mean phi (BI:81), c = phi^T col_cov phi (BI:84)
             df = P3 + scale * T3[ai]                                                       # BI:45; BI:78 with n = 1: df + 1 - 1
-            row_scale = (P2 + scale * T2[ai] - sol["q"]) / df                              # BI:42, :87
+            row_scale = (P2 + scale * T2[ai] - factors[i]["q"][ai]) / df                   # BI:42, :87
             col_scale = sol["c"] + 1.0                                                     # BI:84
             t = rand.student_t(STREAM_INTVAR + i, time, df)                                # BI:104
             draw = sol["m"] + torch.sqrt(row_scale) * t * torch.sqrt(col_scale)            # BI:96-108 (Cholesky of 1 x 1 matrices)
@@ -160,11 +164,11 @@ class Algorithm1:
         rand, time, lam = self._rand(key), int(time), self.forgetting_factor
         suff_stats = self._dev_shapes(suff_stats)
         # :317-320 statistics time update: the factor is applied inside the kernels (scale * T), never materialised
-        aux_state, aux_int_var = self._generate_auxiliary_states(state, time, int_var, suff_stats, scale=lam)   # :323-325
+        aux_state, aux_int_var, factors = self._generate_auxiliary_states(state, time, int_var, suff_stats, scale=lam)   # :323-325
         ll_aux = self.SSM.log_likelihood(self.observations[time], aux_state, self.inputs[time], *aux_int_var)    # :328-341
         a = self.ops.systematic_resample(rand.uniform(STREAM_RESAMPLE, time), (ll_aux + log_weights).contiguous())   # :342-347
         new_state = self._draw_states(rand, time, state, int_var, a)                       # :350-353
-        new_int_var, new_basis = self._draw_int_vars(rand, time, new_state, suff_stats, a, scale=lam)            # :358-367
+        new_int_var, new_basis = self._draw_int_vars(rand, time, new_state, suff_stats, a, factors, scale=lam)   # :358-367
         new_stats = tuple(self.ops.stats_gather_update(lam, a, suff_stats[i], new_basis[i], new_int_var[i].reshape(-1))
                           for i in range(self.N_int))                                      # :370-377
         new_lw = self.SSM.log_likelihood(self.observations[time], new_state, self.inputs[time], *new_int_var) - ll_aux[a.long()]   # :380-390
@@ -201,8 +205,9 @@ class Algorithm3(Algorithm1):
         super().__init__(N_samples, observations, inputs, SSM, 1.0, init_state_mean, init_state_cov, init_int_var_mean, init_int_var_cov,
                          GP_prior, basis_fcn, device=device)
 
-    def _log_base_measure(self, i, stats, ref=None):
-        """vmap(BI.prior_mniw_log_base_measure) (BI:111-124) of prior + stats (+ ref) for n = 1: multigammaln(a, 1) = lgamma(a)."""
+    def _log_base_measure(self, i, stats, ref=None, sol=None):
+        """vmap(BI.prior_mniw_log_base_measure) (BI:111-124) of prior + stats (+ ref) for n = 1: multigammaln(a, 1) = lgamma(a).
+        `sol` = (q, logdet) already computed for the same matrices (the auxiliary pass of this step)."""
         P0, P1, P2, P3 = self.GP_prior[i]
         T0, T1, T2, T3 = stats
         M = P0.numel()
@@ -210,7 +215,8 @@ class Algorithm3(Algorithm1):
         r2 = r3 = 0.0
         if ref is not None:
             R0, R1, r2, r3 = ref[0].reshape(-1).contiguous(), ref[1].contiguous(), ref[2].reshape(()), ref[3].reshape(())
-        sol = self.ops.mniw_solve(P0, P1, T0, T1, R0=R0, R1=R1, want=("q", "logdet"))
+        if sol is None:
+            sol = self.ops.mniw_solve(P0, P1, T0, T1, R0=R0, R1=R1, want=("q", "logdet"))
         nu = P3 + T3 + r3
         Psi = P2 + T2 + r2 - sol["q"]                                                      # BI:115
         return (-0.5 * M * math.log(2 * math.pi) + 0.5 * sol["logdet"] - 0.5 * nu * math.log(2.0) - torch.lgamma(nu / 2)
@@ -224,7 +230,7 @@ class Algorithm3(Algorithm1):
         ref_state = _t(ref_state, dev).reshape(-1) if not isinstance(ref_state, torch.Tensor) else ref_state.reshape(-1)
         ref_int_var = [(_t(v, dev) if not isinstance(v, torch.Tensor) else v).reshape(-1) for v in ref_int_var]
         ref_suff_stats = [tuple((_t(r, dev) if not isinstance(r, torch.Tensor) else r) for r in rs) for rs in ref_suff_stats]
-        aux_state, aux_int_var = self._generate_auxiliary_states(state, time, int_var, suff_stats)                # :66-68
+        aux_state, aux_int_var, factors = self._generate_auxiliary_states(state, time, int_var, suff_stats)      # :66-68
         ll_aux = self.SSM.log_likelihood(self.observations[time], aux_state, self.inputs[time], *aux_int_var)     # :71-84
         lw_aux = ll_aux + log_weights
         a = self.ops.systematic_resample(rand.uniform(STREAM_RESAMPLE, time), lw_aux.contiguous())                # :85-90
@@ -235,7 +241,7 @@ class Algorithm3(Algorithm1):
         else:
             g = torch.zeros(N, dtype=torch.float64, device=dev)
             for i in range(self.N_int):                                                    # :93-108  g_t - g_T
-                g = g + self._log_base_measure(i, suff_stats[i]) - self._log_base_measure(i, suff_stats[i], ref_suff_stats[i])
+                g = g + self._log_base_measure(i, suff_stats[i], sol=factors[i]) - self._log_base_measure(i, suff_stats[i], ref_suff_stats[i])
             if getattr(self, "_Qc", None) is None:
                 Lq = np.linalg.cholesky(self.SSM.process_noise)
                 self._Qc = (_t(np.linalg.inv(Lq), dev).T.contiguous(), -0.5 * Lq.shape[0] * math.log(2 * math.pi) - float(np.sum(np.log(np.diag(Lq)))))
@@ -248,7 +254,7 @@ class Algorithm3(Algorithm1):
         a[-1] = ref_idx                                                                    # :121-127 (clip: SURVEY Q4)
         new_state = self._draw_states(rand, time, state, int_var, a)                       # :130-133
         new_state[-1] = ref_state                                                          # :134
-        new_int_var, new_basis = self._draw_int_vars(rand, time, new_state, suff_stats, a)                       # :139-148
+        new_int_var, new_basis = self._draw_int_vars(rand, time, new_state, suff_stats, a, factors)              # :139-148
         for i in range(self.N_int):
             new_int_var[i][-1] = ref_int_var[i]                                            # :149-152
         new_stats = tuple(self.ops.stats_gather_update(1.0, a, suff_stats[i], new_basis[i], new_int_var[i].reshape(-1))

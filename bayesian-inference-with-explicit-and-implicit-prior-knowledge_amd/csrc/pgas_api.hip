@@ -880,11 +880,13 @@ int pgas_m_rng_student_t(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t
 }
 
 int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int32_t* anc, const double* P0, const double* P1, const double* T0, const double* T1,
-                      const double* R0, const double* R1, const double* phi, double* m, double* cc, double* q, double* logdet, void* sh) {
+                      const double* R0, const double* R1, const double* phi, double* m, double* cc, double* q, double* logdet, double* Lfac, double* wvec,
+                      void* sh) {
     if (!c) return PGAS_E_ARG;
     if (!P0 || !P1 || !T0 || !T1 || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: NULL argument");
     if (M < 1 || M > PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: M = %d outside [1, %d]", M, PG_MN_MAXM);
     if ((R0 == nullptr) != (R1 == nullptr)) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: R0 and R1 must be given together");
+    if ((Lfac == nullptr) != (wvec == nullptr)) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: Lfac and w must be given together");
     if (n == 0) return PGAS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)sh;
@@ -895,8 +897,22 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
     const int waves = 4;
     const dim3 grd((unsigned)((n + waves - 1) / waves)), blk(64 * waves);
     auto kern = M <= 24 ? k_mniw_solve<24> : M <= 32 ? k_mniw_solve<32> : M <= 42 ? k_mniw_solve<42> : M <= 48 ? k_mniw_solve<48> : k_mniw_solve<64>;
-    hipLaunchKernelGGL(kern, grd, blk, (size_t)waves * (M * (M + 1) / 2) * sizeof(double), st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q, logdet, c->d_fail);
+    hipLaunchKernelGGL(kern, grd, blk, (size_t)waves * (M * (M + 1) / 2) * sizeof(double), st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q, logdet, Lfac, wvec, c->d_fail);
     KCHK(c, "k_mniw_solve");
+    return PGAS_OK;
+}
+
+int pgas_m_mniw_trisolve(pgas_ctx* c, int64_t n, int32_t M, const int32_t* anc, const double* Lfac, const double* wvec, const double* phi, double* m,
+                         double* cc, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!Lfac || !wvec || !phi || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: NULL argument");
+    if (M < 1 || M > PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: M = %d outside [1, %d]", M, PG_MN_MAXM);
+    if (n == 0) return PGAS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    const int waves = 4;
+    hipLaunchKernelGGL(k_mniw_trisolve, dim3((unsigned)((n + waves - 1) / waves)), dim3(64 * waves), (size_t)waves * (M * (M + 1) / 2) * sizeof(double),
+                       (hipStream_t)sh, n, M, anc, Lfac, wvec, phi, m, cc);
+    KCHK(c, "k_mniw_trisolve");
     return PGAS_OK;
 }
 

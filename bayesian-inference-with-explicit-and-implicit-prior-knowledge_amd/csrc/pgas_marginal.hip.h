@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
                                                      const double* __restrict__ R1, const double* __restrict__ phi,
                                                      double* __restrict__ m_out, double* __restrict__ c_out,
                                                      double* __restrict__ q_out, double* __restrict__ logdet_out,
-                                                     int32_t* __restrict__ fail_out) {
+                                                     double* __restrict__ Lfac_out, double* __restrict__ w_out, int32_t* __restrict__ fail_out) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
         const double inv = rsqrt_newton(akk);
         const double lk = row[k] * inv;  // L[lane][k] for lane > k (lanes <= k carry values nobody reads)
         if (lane == k) diag = akk;
+        if (Lfac_out && lane < M && lane >= k) A[tl + k] = lane == k ? inv : lk;  // packed factor: L below the diagonal, 1/L_kk on it
         const double bk = readlane_f64(b, k) * inv, wk = readlane_f64(w, k) * inv;
         if (lane == k) {
             b = bk;
@@ -122,6 +123,13 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
             __builtin_amdgcn_sched_barrier(0);
         }
     }
+    if (Lfac_out) {  // hand the factor and w = L^-1 eta0 to k_mniw_trisolve (the children of this particle reuse them)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        double* __restrict__ dst = Lfac_out + (size_t)p * tri_n;
+        for (int e = lane; e < tri_n; e += 64) dst[e] = A[e];
+        if (lane < M) w_out[(size_t)p * M + lane] = w;
+    }
     const double mm = wave_sum_f64(lane < M ? w * b : 0.0);
     const double cc = wave_sum_f64(lane < M ? b * b : 0.0);
     const double qq = wave_sum_f64(lane < M ? w * w : 0.0);
@@ -132,6 +140,44 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
         if (q_out) q_out[p] = qq;
         if (logdet_out) logdet_out[p] = ld;
         if (bad && fail_out) atomicAdd(fail_out, 1);
+    }
+}
+
+// Solve with a stored factor: v = L^-1 phi for the factor of particle anc[p] (written by k_mniw_solve), then
+// m = w . v and c = v . v with w = L^-1 eta0 of the same ancestor.  Same operation order as the substitution inside
+// k_mniw_solve, so the two kernels return identical numbers for identical matrices.  Streaming: 8 (M (M+1)/2 + 2 M) bytes per particle.
+__global__ __launch_bounds__(256) void k_mniw_trisolve(int64_t n, int M, const int32_t* __restrict__ anc, const double* __restrict__ Lfac,
+                                                        const double* __restrict__ wvec, const double* __restrict__ phi,
+                                                        double* __restrict__ m_out, double* __restrict__ c_out) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (p >= n) return;
+    const int64_t src = anc ? (int64_t)anc[p] : p;
+    const int tri_n = M * (M + 1) / 2;
+    double* __restrict__ A = smem + (size_t)wave * tri_n;
+    const double* __restrict__ Ls = Lfac + (size_t)src * tri_n;
+    for (int e = lane; e < tri_n; e += 64) A[e] = Ls[e];
+    double b = 0.0, w = 0.0;
+    if (lane < M) {
+        b = phi[(size_t)p * M + lane];
+        w = wvec[(size_t)src * M + lane];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int tl = lane < M ? lane * (lane + 1) / 2 : 0;
+    const double dinv = lane < M ? A[tl + lane] : 1.0;
+    for (int k = 0; k < M; ++k) {
+        const double bk = readlane_f64(b, k) * readlane_f64(dinv, k);
+        const double lk = (lane > k && lane < M) ? A[tl + k] : 0.0;
+        if (lane == k) b = bk;
+        else if (lane > k) b = PGAS_FMA(-lk, bk, b);
+    }
+    const double mm = wave_sum_f64(lane < M ? w * b : 0.0);
+    const double cc = wave_sum_f64(lane < M ? b * b : 0.0);
+    if (lane == 0) {
+        if (m_out) m_out[p] = mm;
+        if (c_out) c_out[p] = cc;
     }
 }
 

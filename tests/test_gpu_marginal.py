@@ -60,6 +60,12 @@ def test_mniw_solve_against_torch(N, M):
         for k in ref:
             err = (sol[k] - ref[k]).abs().max().item() / max(1.0, ref[k].abs().max().item())
             assert err < 1e-10, (k, err)
+    # stored factor + triangular solve = the full solve, number for number (same operation order)
+    full = ops.mniw_solve(P0, P1, T0, T1, scale=0.999, phi=phi, keep_factor=True)
+    phi2 = torch.randn(N, M, generator=g, dtype=torch.float64).to(dev)
+    tri = ops.mniw_trisolve(full, anc, phi2)
+    again = ops.mniw_solve(P0, P1, T0, T1, scale=0.999, anc=anc, phi=phi2, want=("m", "c"))
+    assert torch.equal(tri["m"], again["m"]) and torch.equal(tri["c"], again["c"])
     # a matrix that is not positive definite is reported, not silently processed
     bad = T1.clone()
     bad[5] = -torch.eye(M, dtype=torch.float64, device=dev) * 10
