@@ -894,10 +894,12 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
         HIPCHK(c, hipMalloc(&c->d_fail, sizeof(int32_t)));
         HIPCHK(c, hipMemsetAsync(c->d_fail, 0, sizeof(int32_t), st));
     }
-    const int waves = 4;
+    const int MT = M <= 24 ? 24 : M <= 32 ? 32 : M <= 42 ? 42 : M <= 48 ? 48 : 64;
+    const int waves = MT == 64 ? 2 : 4;   // LDS: waves x MT (MT+1)/2 doubles <= 64 KB
     const dim3 grd((unsigned)((n + waves - 1) / waves)), blk(64 * waves);
-    auto kern = M <= 24 ? k_mniw_solve<24> : M <= 32 ? k_mniw_solve<32> : M <= 42 ? k_mniw_solve<42> : M <= 48 ? k_mniw_solve<48> : k_mniw_solve<64>;
-    hipLaunchKernelGGL(kern, grd, blk, (size_t)waves * (M * (M + 1) / 2) * sizeof(double), st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q, logdet, Lfac, wvec, c->d_fail);
+    auto kern = MT == 24 ? k_mniw_solve<24> : MT == 32 ? k_mniw_solve<32> : MT == 42 ? k_mniw_solve<42> : MT == 48 ? k_mniw_solve<48> : k_mniw_solve<64>;
+    hipLaunchKernelGGL(kern, grd, blk, (size_t)waves * (MT * (MT + 1) / 2) * sizeof(double), st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q,
+                       logdet, Lfac, wvec, c->d_fail);
     KCHK(c, "k_mniw_solve");
     return PGAS_OK;
 }

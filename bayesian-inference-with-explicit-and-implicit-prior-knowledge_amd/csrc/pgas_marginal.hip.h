@@ -39,8 +39,8 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
 
 // One wave per particle, lane = matrix row, the row held in registers (MT = compile-time row capacity; rows/columns beyond M are
 // padded with the identity, which changes neither the solves nor the determinant).  Right-looking Cholesky with every loop unrolled: column k of L is broadcast lane by
-// lane with v_readlane (wave-uniform indices), so the trailing update is one FMA and two readlanes per matrix element; the
-// forward substitutions of both right-hand sides ride along column by column.  1/sqrt(pivot) comes from v_rsq_f64 plus two
+// lane through LDS (wave-uniform ds_read of the packed factor), so the trailing update costs the VALU one FMA per matrix element;
+// the forward substitutions of both right-hand sides ride along column by column.  1/sqrt(pivot) comes from v_rsq_f64 plus two
 // Newton steps (relative error ~1e-16) instead of an IEEE sqrt and an IEEE division: that chain of ~60 dependent instructions
 // per column was the critical path of the whole kernel.
 __device__ __forceinline__ double rsqrt_newton(double a) {
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
     // Only the lower triangle is needed (lane l uses columns <= l).  Row r is read by lanes 0..r, contiguous in memory, and parked
     // in LDS in packed triangular order; then every lane picks up its own row.  Half the matrix never leaves HBM.
     const int tri_n = M * (M + 1) / 2;
-    double* __restrict__ A = smem + (size_t)wave * tri_n;
+    double* __restrict__ A = smem + (size_t)wave * (MT * (MT + 1) / 2);   // room for the MT padded rows (see the broadcast reads below)
     const double* __restrict__ T1p = T1 + (size_t)src * M * M;
 #pragma unroll 6
     for (int r = 0; r < M; ++r) {
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int tl = lane < M ? lane * (lane + 1) / 2 : 0;
+    const int tl = lane < MT ? lane * (lane + 1) / 2 : 0;
     double row[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
@@ -86,6 +86,8 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
         const double v = A[have ? tl + j : 0];
         row[j] = have ? v : (j == lane ? 1.0 : 0.0);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     double b = 0.0, w = 0.0;  // right-hand sides: lane l holds phi_l and eta0_l
     if (lane < M) {
         w = P0[lane] + scale * T0[(size_t)src * M + lane];
@@ -101,7 +103,12 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
         const double inv = rsqrt_newton(akk);
         const double lk = row[k] * inv;  // L[lane][k] for lane > k (lanes <= k carry values nobody reads)
         if (lane == k) diag = akk;
-        if (Lfac_out && lane < M && lane >= k) A[tl + k] = lane == k ? inv : lk;  // packed factor: L below the diagonal, 1/L_kk on it
+        // column k of the factor goes to LDS in packed row order (L below the diagonal, 1/L_kk on it; the padded rows hold zeros):
+        // the trailing update reads L[j][k] back as a wave-uniform ds_read (a broadcast on the LDS pipe, no VALU slot), and
+        // k_mniw_trisolve gets the same layout
+        if (lane < MT && lane >= k) A[tl + k] = lane == k ? inv : lk;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         const double bk = readlane_f64(b, k) * inv, wk = readlane_f64(w, k) * inv;
         if (lane == k) {
             b = bk;
@@ -110,22 +117,22 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
             b = PGAS_FMA(-lk, bk, b);
             w = PGAS_FMA(-lk, wk, w);
         }
-        // A[lane][j] -= L[lane][k] L[j][k] (only lanes >= j are read later); in groups of 8 so the broadcast values stay in SGPRs
+        // A[lane][j] -= L[lane][k] L[j][k] (only lanes >= j are read later)
         const double nlk = -lk;
 #pragma unroll
-        for (int j0 = k + 1; j0 < MT; j0 += 8) {
+        for (int j0 = k + 1; j0 < MT; j0 += 8) {   // groups of 8 bound the registers the broadcast values occupy
+            double lj[8];
+#pragma unroll
+            for (int j = j0; j < j0 + 8 && j < MT; ++j) lj[j - j0] = A[j * (j + 1) / 2 + k];   // eight reads in flight
 #pragma unroll
             for (int j = j0; j < j0 + 8 && j < MT; ++j) {
-                row[j] = PGAS_FMA(nlk, readlane_f64(lk, j), row[j]);
-                asm volatile("" : "+v"(row[j]));  // consume the broadcast here: otherwise the compiler defers all updates of column j
-                                                  // to iteration j and keeps (spills) every broadcast value until then
+                row[j] = PGAS_FMA(nlk, lj[j - j0], row[j]);
+                asm volatile("" : "+v"(row[j]));   // consume the broadcast here: otherwise every update of column j is deferred to iteration j
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (Lfac_out) {  // hand the factor and w = L^-1 eta0 to k_mniw_trisolve (the children of this particle reuse them)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
         double* __restrict__ dst = Lfac_out + (size_t)p * tri_n;
         for (int e = lane; e < tri_n; e += 64) dst[e] = A[e];
         if (lane < M) w_out[(size_t)p * M + lane] = w;
