@@ -50,6 +50,55 @@ __device__ __forceinline__ double rsqrt_newton(double a) {
     y = y * PGAS_FMA(-h * y, y, 1.5);
     return y;
 }
+// Column k of the factorisation, k a template parameter: the recursion unrolls the outer loop at compile time whatever the
+// optimiser's unroll budget is (with `#pragma unroll` the 48- and 64-row instantiations fell back to a runtime loop and their
+// register-resident rows to scratch memory).
+template <int MT, int K>
+struct CholColumn {
+    static __device__ __forceinline__ void run(double (&row)[MT], double& b, double& w, double& diag, int& bad, double* __restrict__ A, int tl,
+                                               int lane) {
+        constexpr int k = K;
+        const double akk = readlane_f64(row[k], k);
+        if (!(akk > 0.0)) bad = 1;
+        const double inv = rsqrt_newton(akk);
+        const double lk = row[k] * inv;  // L[lane][k] for lane > k (lanes <= k carry values nobody reads)
+        if (lane == k) diag = akk;
+        // column k of the factor goes to LDS in packed row order (L below the diagonal, 1/L_kk on it; the padded rows hold zeros):
+        // the trailing update reads L[j][k] back as a wave-uniform ds_read (a broadcast on the LDS pipe, no VALU slot), and
+        // k_mniw_trisolve gets the same layout
+        if (lane < MT && lane >= k) A[tl + k] = lane == k ? inv : lk;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const double bk = readlane_f64(b, k) * inv, wk = readlane_f64(w, k) * inv;
+        if (lane == k) {
+            b = bk;
+            w = wk;
+        } else if (lane > k) {
+            b = PGAS_FMA(-lk, bk, b);
+            w = PGAS_FMA(-lk, wk, w);
+        }
+        // A[lane][j] -= L[lane][k] L[j][k] (only lanes >= j are read later)
+        const double nlk = -lk;
+#pragma unroll
+        for (int j0 = k + 1; j0 < MT; j0 += 8) {   // groups of 8 bound the registers the broadcast values occupy
+            double lj[8];
+#pragma unroll
+            for (int j = j0; j < j0 + 8 && j < MT; ++j) lj[j - j0] = A[j * (j + 1) / 2 + k];   // eight reads in flight
+#pragma unroll
+            for (int j = j0; j < j0 + 8 && j < MT; ++j) {
+                row[j] = PGAS_FMA(nlk, lj[j - j0], row[j]);
+                asm volatile("" : "+v"(row[j]));   // consume the broadcast here: otherwise every update of column j is deferred to iteration j
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        CholColumn<MT, K + 1>::run(row, b, w, diag, bad, A, tl, lane);
+    }
+};
+template <int MT>
+struct CholColumn<MT, MT> {
+    static __device__ __forceinline__ void run(double (&)[MT], double&, double&, double&, int&, double* __restrict__, int, int) {}
+};
+
 template <int MT>
 __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double scale, const int32_t* __restrict__ anc, const double* __restrict__ P0,
                                                      const double* __restrict__ P1, const double* __restrict__ T0,
@@ -96,42 +145,7 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
     }
     double diag = 1.0;  // pivot of this lane's column (before the square root)
     int bad = 0;
-#pragma unroll
-    for (int k = 0; k < MT; ++k) {
-        const double akk = readlane_f64(row[k], k);
-        if (!(akk > 0.0)) bad = 1;
-        const double inv = rsqrt_newton(akk);
-        const double lk = row[k] * inv;  // L[lane][k] for lane > k (lanes <= k carry values nobody reads)
-        if (lane == k) diag = akk;
-        // column k of the factor goes to LDS in packed row order (L below the diagonal, 1/L_kk on it; the padded rows hold zeros):
-        // the trailing update reads L[j][k] back as a wave-uniform ds_read (a broadcast on the LDS pipe, no VALU slot), and
-        // k_mniw_trisolve gets the same layout
-        if (lane < MT && lane >= k) A[tl + k] = lane == k ? inv : lk;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const double bk = readlane_f64(b, k) * inv, wk = readlane_f64(w, k) * inv;
-        if (lane == k) {
-            b = bk;
-            w = wk;
-        } else if (lane > k) {
-            b = PGAS_FMA(-lk, bk, b);
-            w = PGAS_FMA(-lk, wk, w);
-        }
-        // A[lane][j] -= L[lane][k] L[j][k] (only lanes >= j are read later)
-        const double nlk = -lk;
-#pragma unroll
-        for (int j0 = k + 1; j0 < MT; j0 += 8) {   // groups of 8 bound the registers the broadcast values occupy
-            double lj[8];
-#pragma unroll
-            for (int j = j0; j < j0 + 8 && j < MT; ++j) lj[j - j0] = A[j * (j + 1) / 2 + k];   // eight reads in flight
-#pragma unroll
-            for (int j = j0; j < j0 + 8 && j < MT; ++j) {
-                row[j] = PGAS_FMA(nlk, lj[j - j0], row[j]);
-                asm volatile("" : "+v"(row[j]));   // consume the broadcast here: otherwise every update of column j is deferred to iteration j
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
+    CholColumn<MT, 0>::run(row, b, w, diag, bad, A, tl, lane);
     if (Lfac_out) {  // hand the factor and w = L^-1 eta0 to k_mniw_trisolve (the children of this particle reuse them)
         double* __restrict__ dst = Lfac_out + (size_t)p * tri_n;
         for (int e = lane; e < tri_n; e += 64) dst[e] = A[e];

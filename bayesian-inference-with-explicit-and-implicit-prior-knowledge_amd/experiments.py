@@ -211,7 +211,8 @@ class MarginalProblem:
         return cls(process_noise=self.process_noise, output_noise=self.output_noise, transition_model=f, output_model=g)
 
     def basis_fcn(self):
-        return [lambda state, input, b=b: b.batch(state, input) for b in self.basis]
+        """basis_fcn[i](state (N,n_x), input) -> (N,M); entries of `basis` are BasisMap descriptors or plain batched callables."""
+        return [(lambda state, input, b=b: b.batch(state, input)) if hasattr(b, "batch") else b for b in self.basis]
 
 
 def smo_marginal(T=750, seed=12345678):
@@ -263,3 +264,106 @@ def toy_marginal(T=40, seed=12345678):
     fx_true = 10 * np.sinc(X[:, 0] / 7)
     return MarginalProblem("Toy", pt.observations, pt.inputs, np.zeros((1, 1)), np.diag([4.0]), np.array([0.0]), np.diag([1e-4]),
                            [np.array([10 * np.sinc(0.0)])], [np.diag([4.0])], [pt.GP_prior], [pt.basis_fcn], 1.0, model, X, [fx_true])
+
+
+class _SlipAngleBasis:
+    """basis_fcn_f / basis_fcn_r of src/Vehicle.py:146-153: the 1-D Hilbert basis evaluated at the front / rear tyre side-slip angle
+    (f_alpha, :51-58).  Batched, NumPy or torch."""
+
+    def __init__(self, basis, rear, l_f=1.16, l_r=1.47):
+        self.map, self.rear, self.l_f, self.l_r = basis.on([0]), rear, l_f, l_r
+
+    def alpha(self, state, input):
+        xp = np if isinstance(state, np.ndarray) else __import__("torch")
+        if self.rear:
+            return -xp.arctan((state[:, 1] - state[:, 0] * self.l_r) / input[1])
+        return input[0] - xp.arctan((state[:, 1] + state[:, 0] * self.l_f) / input[1])
+
+    def batch(self, state, input):
+        return self.map.batch(self.alpha(state, input).reshape(-1, 1), None)
+
+    def __call__(self, state, input):
+        return self.batch(state, input)
+
+
+def vehicle_marginal(T=1500, seed=12345678, M=20):
+    """src/Vehicle.py:14-292: lateral vehicle dynamics, the two tyre friction curves mu_y(alpha_f), mu_y(alpha_r) are the latent
+    functions (two scalar interface variables).  M = 20 is the reference's basis size; BASELINE.json configs[2] asks for a
+    larger set (the device kernels take M <= 64)."""
+    m, I_zz, l_f, l_r, g, mu_x = 1720.0, 1827.5, 1.16, 1.47, 9.81, 0.9    # :17-22
+    dt = 0.02                                                              # :183
+    pv = vehicle_pgas(T=T, seed=seed, M=27)                                # same simulated states and inputs (:199-257)
+    X, ctrl = pv.X_true, pv.inputs
+    F_zf, F_zr = m * g * l_r / (l_f + l_r), m * g * l_f / (l_f + l_r)     # :30-36
+    mu, B, C, E = 0.9, 10.0, 1.9, 0.97
+
+    def mu_y(alpha):                                                       # :40-47
+        return mu * np.sin(C * np.arctan(B * (1 - E) * np.tan(alpha) + E * np.arctan(B * np.tan(alpha))))
+
+    basis, sd = generate_Hilbert_BasisFunction(M, np.array([-30 / 180 * np.pi, 30 / 180 * np.pi]), 2 / 180 * np.pi, 50, idx_start=2, idx_step=2)   # :134-143
+    bf, br = _SlipAngleBasis(basis, rear=False), _SlipAngleBasis(basis, rear=True)
+    mu_f_true = mu_y(np.array([bf.alpha(X[t:t + 1], ctrl[t])[0] for t in range(T)]))
+    mu_r_true = mu_y(np.array([br.alpha(X[t:t + 1], ctrl[t])[0] for t in range(T)]))
+
+    def model(xp):
+        def dxf(x, u, mf, mr):                                             # :62-86
+            dv_y = (F_zf * mf * xp.cos(u[0]) + F_zr * mr + F_zf * mu_x * xp.sin(u[0])) / m - u[1] * x[:, 0]
+            ddpsi = (l_f * F_zf * mf * xp.cos(u[0]) - l_r * F_zr * mr + l_f * F_zf * mu_x * xp.sin(u[0])) / I_zz
+            return xp.stack([ddpsi, dv_y], 1)
+
+        def f_x(state, input, *int_var):                                   # :90-100, :213-215
+            mf, mr = int_var[0].reshape(-1), int_var[1].reshape(-1)
+            k1 = dxf(state, input, mf, mr)
+            k2 = dxf(state + dt * k1 / 2.0, input, mf, mr)
+            k3 = dxf(state + dt * k2 / 2.0, input, mf, mr)
+            k4 = dxf(state + dt * k3, input, mf, mr)
+            return state + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+        def f_y(state, input, *int_var):                                   # :104-131, :216-218
+            mf, mr = int_var[0].reshape(-1), int_var[1].reshape(-1)
+            dv_y = (F_zf * mf * xp.cos(input[0]) + F_zr * mr + F_zf * mu_x * xp.sin(input[0])) / m - input[1] * state[:, 0]
+            return xp.tanh(xp.stack([state[:, 0], dv_y], 1))
+
+        return f_x, f_y
+
+    prior = prior_mniw_2naturalPara(np.zeros((1, M)), np.diag(sd), np.eye(1), 0)   # :157-173
+    R, Q = np.diag([0.001 / 180 * np.pi, 1e-3]), np.diag([1e-8, 1e-8])    # :195-196
+    # observations of THIS model: y = tanh([yaw rate, lateral acceleration]) + noise (:254-255)
+    rng = np.random.default_rng(seed + 1)
+    f, gy = model(np)
+    Y = np.zeros((T, 2))
+    for t in range(1, T):
+        Y[t] = gy(X[t:t + 1], ctrl[t], np.array([[mu_f_true[t]]]), np.array([[mu_r_true[t]]]))[0] + np.sqrt(np.diag(R)) * rng.standard_normal(2)
+    return MarginalProblem("Vehicle", Y, ctrl, Q, R, np.array([0.0, 0.0]), np.diag([1e-4, 1e-4]), [np.array([0.0]), np.array([0.0])],
+                           [np.diag([1e-4]), np.diag([1e-4])], [prior, prior], [bf, br], 0.999, model, X, [mu_f_true, mu_r_true])
+
+
+def emps_marginal(T=2000, seed=12345678):
+    """src/EMPS.py:40-240: electro-mechanical positioning system, the friction force F(dq) is the latent function; synthetic data from
+    the reference's linear friction model (:169-193), as in emps_pgas."""
+    Mass, dt = 95.11, 0.01
+    pe = emps_pgas(T=T, seed=seed, M=27)
+    X, tau = pe.X_true, pe.inputs
+    F_true = 203.5 * X[:, 1] + 20.39 * np.sign(X[:, 1]) - 3.16             # :169-173 rearranged: ddq = (tau - F) / M
+    basis, sd = generate_Hilbert_BasisFunction(9, np.array([-0.2, 0.2]), 0.4 / 9, 20)   # :81-85
+    prior = prior_mniw_2naturalPara(np.zeros((1, 9)), np.diag(sd), np.eye(1) * 4, 2)    # :92-96
+
+    def model(xp):
+        def dxf(x, t_, F):                                                 # :158-165
+            return xp.stack([x[:, 1], (t_ - F) / Mass], 1)
+
+        def f_x(state, input, *int_var):                                   # :177-183, :205-207
+            t_, F = input.reshape(-1)[0], int_var[0].reshape(-1)
+            k1 = dxf(state, t_, F)
+            k2 = dxf(state + dt * k1 / 2, t_, F)
+            k3 = dxf(state + dt * k2 / 2, t_, F)
+            k4 = dxf(state + dt * k3, t_, F)
+            return state + dt / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+        def f_y(state, input, *int_var):                                   # :197-198, :208
+            return state[:, 0:1]
+
+        return f_x, f_y
+
+    return MarginalProblem("EMPS", pe.observations, tau.reshape(-1, 1), np.diag([1e-6, 1e-7]), np.diag([1e-4]), pe.init_state_mean, np.diag([1e-5, 1e-6]),
+                           [np.array([0.0])], [np.diag([1e-12])], [prior], [basis.on([1])], 0.999, model, X, [F_true])

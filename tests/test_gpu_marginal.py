@@ -124,28 +124,34 @@ def _close(gpu, ref, what, tol=1e-8):
     assert err < tol, f"{what}: relative error {err:.3e}"
 
 
-@pytest.mark.parametrize("name,N", [("smo", 200), ("toy", 200), ("smo", 1500)])
+def _problem(name, T=8):
+    return {"smo": experiments.smo_marginal, "toy": experiments.toy_marginal, "vehicle": experiments.vehicle_marginal,
+            "emps": experiments.emps_marginal}[name](T=T)
+
+
+@pytest.mark.parametrize("name,N", [("smo", 200), ("toy", 200), ("smo", 1500), ("vehicle", 300), ("emps", 300)])
 def test_algorithm1_matches_restatement(name, N):
-    pb = experiments.smo_marginal(T=8) if name == "smo" else experiments.toy_marginal(T=8)
+    pb = _problem(name)
     ref = marginal_oracle(pb, N)(CanonRand(SEED, N))
     got = _device_alg(pb, N)(SEED)
     assert np.array_equal(got[4].cpu().numpy(), ref[4]), "ancestor_trace"
     _close(got[0], ref[0], "state_trace")
-    _close(got[1][0], ref[1][0], "int_var_trace")
-    for j in range(4):
-        _close(got[2][0][j], ref[2][0][j], f"suff_stats_trace[{j}]")
-        _close(got[5][0][j], ref[5][0][j], f"suff_stats[{j}]")
+    for i in range(len(pb.basis)):          # Vehicle carries two latent functions
+        _close(got[1][i], ref[1][i], f"int_var_trace[{i}]")
+        for j in range(4):
+            _close(got[2][i][j], ref[2][i][j], f"suff_stats_trace[{i}][{j}]")
+            _close(got[5][i][j], ref[5][i][j], f"suff_stats[{i}][{j}]")
     _close(got[3], ref[3], "weights_trace")
     _close(got[6], ref[6], "obs_trace")
     _close(got[7], ref[7], "log_likelihood", tol=1e-7)
     assert got[2][0][0].shape == (pb.T, pb.GP_prior[0][0].shape[0], 1) and got[5][0][2].shape == (N, 1, 1)   # the reference's shapes
 
 
-@pytest.mark.parametrize("name,N", [("smo", 150), ("toy", 150)])
+@pytest.mark.parametrize("name,N", [("smo", 150), ("toy", 150), ("vehicle", 200)])
 def test_algorithm3_matches_restatement(name, N):
-    pb = experiments.smo_marginal(T=8) if name == "smo" else experiments.toy_marginal(T=8)
+    pb = _problem(name)
     oracle = marginal_oracle(pb, N, "Algorithm3")
-    ref_x, ref_iv = pb.X_true, [pb.int_var_true[0]]
+    ref_x, ref_iv = pb.X_true, list(pb.int_var_true)
     ref_stats = mo.trajectory_stats(oracle, ref_x, ref_iv)
     traj, ivt, tr = oracle(CanonRand(SEED, N), ref_x, ref_iv, ref_stats)
     alg = _device_alg(pb, N, "Algorithm3")
@@ -154,7 +160,8 @@ def test_algorithm3_matches_restatement(name, N):
     _close(gtr["state_trace"], tr["state_trace"], "state_trace")
     _close(gtr["log_weights"], tr["log_weights"], "final log-weights", tol=1e-7)
     _close(gt, traj, "state trajectory")
-    _close(gi[0], ivt[0], "interface-variable trajectory")
+    for i in range(len(pb.basis)):
+        _close(gi[i], ivt[i], f"interface-variable trajectory {i}")
 
 
 def test_algorithm2_runs_and_returns_reference_shapes():

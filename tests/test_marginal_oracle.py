@@ -36,9 +36,10 @@ def test_batched_mniw_algebra_matches_per_particle_functions():
         assert np.isclose(mo._log_base_measure_b(eta0, eta1, eta2, np.full(N, 5.0))[p], o.prior_mniw_log_base_measure(eta0[p], eta1[p], eta2[p], 5.0))
 
 
-@pytest.mark.parametrize("name", ["smo", "toy"])
+@pytest.mark.parametrize("name", ["smo", "toy", "vehicle", "emps"])
 def test_algorithm1_invariants(name):
-    pb = experiments.smo_marginal(T=12) if name == "smo" else experiments.toy_marginal(T=12)
+    pb = {"smo": experiments.smo_marginal, "toy": experiments.toy_marginal, "vehicle": experiments.vehicle_marginal,
+          "emps": experiments.emps_marginal}[name](T=12)
     N = 80
     alg = marginal_oracle(pb, N)
     st, iv, sst, w, anc, ss, obs, ll = alg(CanonRand(SEED, N))

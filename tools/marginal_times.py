@@ -13,16 +13,18 @@ def ev(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3   # us
 
+MODEL = os.environ.get("MODEL", "smo")
+MB = int(os.environ.get("M", "0"))
 for N in [int(a) for a in (sys.argv[1:] or ["200", "16384", "131072", "1048576"])]:
     T = 24 if N > 100000 else 60
-    pb = experiments.smo_marginal(T=T)
+    pb = experiments.smo_marginal(T=T) if MODEL == "smo" else experiments.vehicle_marginal(T=T, M=MB or 20)
     ssm = pb.ssm(pgas_amd.StateSpaceModel, torch)
     alg = pgas_amd.Algorithm1(N_samples=N, observations=pb.observations, inputs=pb.inputs, SSM=ssm, forgetting_factor=pb.forgetting_factor,
                               init_state_mean=pb.init_state_mean, init_state_cov=pb.init_state_cov, init_int_var_mean=pb.init_int_var_mean,
                               init_int_var_cov=pb.init_int_var_cov, GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn())
     rand = alg._rand(1)
     st, iv, sst, lw, anc, ss = alg._init_algorithm(rand)
-    x, l, v = st[0], lw[0], [iv[0][0]]
+    x, l, v = st[0], lw[0], [iv[i][0] for i in range(len(iv))]
     for t in range(1, 4):
         l, x, v, ss, a = alg.step(rand, t, l, x, v, ss)
     torch.cuda.synchronize()
@@ -32,9 +34,9 @@ for N in [int(a) for a in (sys.argv[1:] or ["200", "16384", "131072", "1048576"]
         l, x, v, ss, a = alg.step(rand, t, l, x, v, ss)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / nst
-    M = 41
+    M = alg.dim_basis[0]
     ops, (P0, P1, _, _) = alg.ops, alg.GP_prior[0]
-    phi = pb.basis[0].batch(x, None).contiguous()
+    phi = alg.basis_fcn[0](x, alg.inputs[5]).contiguous()
     xi = v[0].reshape(-1).contiguous()
     us_solve = ev(lambda: ops.mniw_solve(P0, P1, ss[0][0], ss[0][1], scale=0.999, anc=a, phi=phi, want=("m", "c", "q")))
     fac = ops.mniw_solve(P0, P1, ss[0][0], ss[0][1], scale=0.999, phi=phi, want=("m", "q", "logdet"), keep_factor=True)
@@ -45,7 +47,7 @@ for N in [int(a) for a in (sys.argv[1:] or ["200", "16384", "131072", "1048576"]
     w = torch.softmax(l, 0)
     us_wsum = ev(lambda: alg._weighted(ss[0], w))
     bytes_stats = 8.0 * (M * M + M + 2) * N
-    print(f"N={N:8d}: step {dt*1e3:8.3f} ms = {N/dt:.3e} particle-steps/s | k_mniw_solve+store {us_fac:9.1f} us | k_mniw_trisolve {us_tri:8.1f} us ({8.0*(M*(M+1)/2+2*M)*N/us_tri/1e3:7.1f} GB/s) | k_mniw_solve {us_solve:9.1f} us ({bytes_stats/us_solve/1e3:7.1f} GB/s read) | "
+    print(f"{pb.name} M={M} x{len(iv)} N={N:8d}: step {dt*1e3:8.3f} ms = {N/dt:.3e} particle-steps/s | k_mniw_solve+store {us_fac:9.1f} us | k_mniw_trisolve {us_tri:8.1f} us ({8.0*(M*(M+1)/2+2*M)*N/us_tri/1e3:7.1f} GB/s) | k_mniw_solve {us_solve:9.1f} us ({bytes_stats/us_solve/1e3:7.1f} GB/s read) | "
           f"k_stats_gather_update {us_upd:9.1f} us ({2*bytes_stats/us_upd/1e3:7.1f} GB/s r+w) | resample {us_rs:7.1f} us | k_weighted_stats {us_wsum:9.1f} us ({bytes_stats/us_wsum/1e3:7.1f} GB/s read)", flush=True)
     del alg, ss, st, iv, sst, lw, anc
     torch.cuda.empty_cache()
