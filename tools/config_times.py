@@ -17,7 +17,7 @@ for name, mk in [c for c in cfgs if os.environ.get("ONLY", "") in c[0]]:
     if os.environ.get("CHUNK"):
         csmc.engine.set_option(1, int(os.environ["CHUNK"]))
     csmc(1, pb.X_true, A, S); torch.cuda.synchronize()
-    csmc.engine.set_profiling(int(os.environ.get('PROFILE', '1')))
+    csmc.engine.set_profiling(int(os.environ.get('PROFILE', '3')))   # every 3rd launch: a stride that is not a divisor of the propagate chunk
     dt = 1e9
     for k in range(3):   # best of 3: a fresh engine occasionally sees one ~50 ms driver hiccup in its first sweeps (tools/seq_check.py)
         t0 = time.perf_counter(); csmc(2 + k, pb.X_true, A, S); torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
