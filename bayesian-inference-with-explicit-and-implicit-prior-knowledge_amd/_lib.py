@@ -108,9 +108,9 @@ def load():
     L.pgas_m_rng_student_t.restype = C.c_int
     L.pgas_m_rng_student_t.argtypes = [vp, u64, u32, u32, i64, i64, vp, vp, vp]
     L.pgas_m_mniw_solve.restype = C.c_int
-    L.pgas_m_mniw_solve.argtypes = [vp, i64, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_mniw_solve.argtypes = [vp, i64, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pgas_m_mniw_trisolve.restype = C.c_int
-    L.pgas_m_mniw_trisolve.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_mniw_trisolve.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp]
     L.pgas_m_weighted_stats.restype = C.c_int
     L.pgas_m_weighted_stats.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pgas_m_check.restype = C.c_int
@@ -400,12 +400,11 @@ class MarginalOps:
 
     def mniw_solve(self, P0, P1, T0, T1, scale=1.0, anc=None, R0=None, R1=None, phi=None, want=("m", "c", "q", "logdet"), keep_factor=False):
         """eta0 = P0 + scale T0[anc] (+R0), eta1 = P1 + scale T1[anc] (+R1) per particle -> dict of (n,) tensors (see pgas_m_mniw_solve).
-        keep_factor=True adds "L" (n, M(M+1)/2) and "w" (n, M) for mniw_trisolve."""
+        keep_factor=True adds "L" (n, (M+2)(M+3)/2), the packed factor with the right-hand-side rows, for mniw_trisolve."""
         n, M = T0.shape[0], T0.shape[1]
         out = {k: self._vec(n) for k in want}
         if keep_factor:
-            out["L"] = torch.empty((n, M * (M + 1) // 2), dtype=torch.float64, device=self.device)
-            out["w"] = torch.empty((n, M), dtype=torch.float64, device=self.device)
+            out["L"] = torch.empty((n, (M + 2) * (M + 3) // 2), dtype=torch.float64, device=self.device)
         a = None if anc is None else anc.to(device=self.device, dtype=torch.int32).contiguous()
         for arr in (P0, P1, T0, T1, R0, R1, phi):
             if arr is not None and not (arr.is_contiguous() and arr.dtype == torch.float64 and arr.device == self.device):
@@ -414,18 +413,18 @@ class MarginalOps:
             raise ValueError("mniw_solve: one ancestor index per particle expected")
         self.eng._chk(self.lib.pgas_m_mniw_solve(self.eng._h, n, M, float(scale), self._ptr(a), P0.data_ptr(), P1.data_ptr(), T0.data_ptr(), T1.data_ptr(),
                                                  self._ptr(R0), self._ptr(R1), self._ptr(phi), self._ptr(out.get("m")), self._ptr(out.get("c")),
-                                                 self._ptr(out.get("q")), self._ptr(out.get("logdet")), self._ptr(out.get("L")), self._ptr(out.get("w")),
-                                                 self.eng._stream()), "pgas_m_mniw_solve")
+                                                 self._ptr(out.get("q")), self._ptr(out.get("logdet")), self._ptr(out.get("L")), self.eng._stream()),
+                      "pgas_m_mniw_solve")
         return out
 
     def mniw_trisolve(self, fac, anc, phi):
         """m = w[anc] . v, c = v . v with v = L[anc]^-1 phi for a factor kept by mniw_solve(keep_factor=True)."""
         n, M = phi.shape
         a = None if anc is None else anc.to(device=self.device, dtype=torch.int32).contiguous()
-        if fac["L"].shape != (n, M * (M + 1) // 2) or fac["w"].shape != (n, M) or (a is not None and a.numel() != n):
+        if fac["L"].shape != (n, (M + 2) * (M + 3) // 2) or (a is not None and a.numel() != n):
             raise ValueError("mniw_trisolve: operand shapes do not match")
         m, c = self._vec(n), self._vec(n)
-        self.eng._chk(self.lib.pgas_m_mniw_trisolve(self.eng._h, n, M, self._ptr(a), fac["L"].data_ptr(), fac["w"].data_ptr(), phi.contiguous().data_ptr(),
+        self.eng._chk(self.lib.pgas_m_mniw_trisolve(self.eng._h, n, M, self._ptr(a), fac["L"].data_ptr(), phi.contiguous().data_ptr(),
                                                     m.data_ptr(), c.data_ptr(), self.eng._stream()), "pgas_m_mniw_trisolve")
         return {"m": m, "c": c}
 

@@ -880,13 +880,11 @@ int pgas_m_rng_student_t(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t
 }
 
 int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int32_t* anc, const double* P0, const double* P1, const double* T0, const double* T1,
-                      const double* R0, const double* R1, const double* phi, double* m, double* cc, double* q, double* logdet, double* Lfac, double* wvec,
-                      void* sh) {
+                      const double* R0, const double* R1, const double* phi, double* m, double* cc, double* q, double* logdet, double* Lfac, void* sh) {
     if (!c) return PGAS_E_ARG;
     if (!P0 || !P1 || !T0 || !T1 || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: NULL argument");
     if (M < 1 || M > PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: M = %d outside [1, %d]", M, PG_MN_MAXM);
     if ((R0 == nullptr) != (R1 == nullptr)) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: R0 and R1 must be given together");
-    if ((Lfac == nullptr) != (wvec == nullptr)) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: Lfac and w must be given together");
     if (n == 0) return PGAS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)sh;
@@ -894,26 +892,25 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
         HIPCHK(c, hipMalloc(&c->d_fail, sizeof(int32_t)));
         HIPCHK(c, hipMemsetAsync(c->d_fail, 0, sizeof(int32_t), st));
     }
-    const int MT = M <= 24 ? 24 : M <= 32 ? 32 : M <= 42 ? 42 : M <= 48 ? 48 : 64;
+    const int MT = M <= 22 ? 24 : M <= 30 ? 32 : M <= 42 ? 44 : M <= 46 ? 48 : 64;   // rows: M + 2 (the right-hand sides ride along)
     const int waves = MT == 64 ? 2 : 4;   // LDS: waves x MT (MT+1)/2 doubles <= 64 KB
     const dim3 grd((unsigned)((n + waves - 1) / waves)), blk(64 * waves);
-    auto kern = MT == 24 ? k_mniw_solve<24> : MT == 32 ? k_mniw_solve<32> : MT == 42 ? k_mniw_solve<42> : MT == 48 ? k_mniw_solve<48> : k_mniw_solve<64>;
+    auto kern = MT == 24 ? k_mniw_solve<24> : MT == 32 ? k_mniw_solve<32> : MT == 44 ? k_mniw_solve<44> : MT == 48 ? k_mniw_solve<48> : k_mniw_solve<64>;
     hipLaunchKernelGGL(kern, grd, blk, (size_t)waves * (MT * (MT + 1) / 2) * sizeof(double), st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q,
-                       logdet, Lfac, wvec, c->d_fail);
+                       logdet, Lfac, c->d_fail);
     KCHK(c, "k_mniw_solve");
     return PGAS_OK;
 }
 
-int pgas_m_mniw_trisolve(pgas_ctx* c, int64_t n, int32_t M, const int32_t* anc, const double* Lfac, const double* wvec, const double* phi, double* m,
-                         double* cc, void* sh) {
+int pgas_m_mniw_trisolve(pgas_ctx* c, int64_t n, int32_t M, const int32_t* anc, const double* Lfac, const double* phi, double* m, double* cc, void* sh) {
     if (!c) return PGAS_E_ARG;
-    if (!Lfac || !wvec || !phi || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: NULL argument");
+    if (!Lfac || !phi || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: NULL argument");
     if (M < 1 || M > PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: M = %d outside [1, %d]", M, PG_MN_MAXM);
     if (n == 0) return PGAS_OK;
     HIPCHK(c, hipSetDevice(c->device));
     const int waves = 4;
-    hipLaunchKernelGGL(k_mniw_trisolve, dim3((unsigned)((n + waves - 1) / waves)), dim3(64 * waves), (size_t)waves * (M * (M + 1) / 2) * sizeof(double),
-                       (hipStream_t)sh, n, M, anc, Lfac, wvec, phi, m, cc);
+    hipLaunchKernelGGL(k_mniw_trisolve, dim3((unsigned)((n + waves - 1) / waves)), dim3(64 * waves),
+                       (size_t)waves * ((M + 2) * (M + 3) / 2) * sizeof(double), (hipStream_t)sh, n, M, anc, Lfac, phi, m, cc);
     KCHK(c, "k_mniw_trisolve");
     return PGAS_OK;
 }

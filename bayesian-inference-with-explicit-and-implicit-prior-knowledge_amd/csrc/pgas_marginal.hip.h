@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void k_rng_student_t(uint64_t seed, uint32_t s
     out[p] = pgas_rng_student_t(seed, stream, t, (uint64_t)(p0 + p), nu[p]);
 }
 
-#define PG_MN_MAXM 64      // one matrix row per lane; particles per workgroup = blockDim.x / 64 (one wave each)
+#define PG_MN_MAXM 62      // one matrix row per lane plus the two right-hand-side rows; particles per workgroup = blockDim.x / 64
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
 #pragma unroll
@@ -37,12 +37,18 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     return v;
 }
 
-// One wave per particle, lane = matrix row, the row held in registers (MT = compile-time row capacity; rows/columns beyond M are
-// padded with the identity, which changes neither the solves nor the determinant).  Right-looking Cholesky with every loop unrolled: column k of L is broadcast lane by
-// lane through LDS (wave-uniform ds_read of the packed factor), so the trailing update costs the VALU one FMA per matrix element;
-// the forward substitutions of both right-hand sides ride along column by column.  1/sqrt(pivot) comes from v_rsq_f64 plus two
-// Newton steps (relative error ~1e-16) instead of an IEEE sqrt and an IEEE division: that chain of ~60 dependent instructions
-// per column was the critical path of the whole kernel.
+// k_mniw_solve: one wave per particle, lane = matrix row, the row held in registers (MT = compile-time row capacity).
+//
+// The two right-hand sides ride along as two EXTRA ROWS of the matrix: with
+//        [ eta1   .   . ]                      [ L            ]
+//    B = [ phi^T  0   . ]   elimination of the first M columns (right-looking Cholesky) leaves rows M, M+1 = [ v^T ; w^T ],
+//        [ eta0^T 0   0 ]   v = L^-1 phi, w = L^-1 eta0, and the Schur complement of the corner = -[ v.v  . ; w.v  w.w ],
+// i.e. c, m and q fall out of the same FMAs that factorise eta1 -- no separate substitution, no reductions.
+// Only the lower triangle is touched: row r is read by lanes 0..r (contiguous in memory), parked in LDS in packed triangular
+// order, and every lane picks up its own row.  Column k of the factor is broadcast lane by lane through LDS (wave-uniform
+// ds_read of the packed factor), so the trailing update costs the VALU one FMA per matrix element.  1/sqrt(pivot) comes from
+// v_rsq_f64 plus two Newton steps (relative error ~1e-16) instead of an IEEE sqrt and an IEEE division: that chain of ~60
+// dependent instructions per column was the critical path of the first version.
 __device__ __forceinline__ double rsqrt_newton(double a) {
     double y = __builtin_amdgcn_rsq(a);
     const double h = 0.5 * a;
@@ -51,54 +57,44 @@ __device__ __forceinline__ double rsqrt_newton(double a) {
     return y;
 }
 // Column k of the factorisation, k a template parameter: the recursion unrolls the outer loop at compile time whatever the
-// optimiser's unroll budget is (with `#pragma unroll` the 48- and 64-row instantiations fell back to a runtime loop and their
+// optimiser's unroll budget is (with `#pragma unroll` the larger instantiations fell back to a runtime loop and their
 // register-resident rows to scratch memory).
 template <int MT, int K>
 struct CholColumn {
-    static __device__ __forceinline__ void run(double (&row)[MT], double& b, double& w, double& diag, int& bad, double* __restrict__ A, int tl,
-                                               int lane) {
+    static __device__ __forceinline__ void run(double (&row)[MT], int M, double* __restrict__ A, int tl, int lane) {
         constexpr int k = K;
-        const double akk = readlane_f64(row[k], k);
-        if (!(akk > 0.0)) bad = 1;
-        const double inv = rsqrt_newton(akk);
-        const double lk = row[k] * inv;  // L[lane][k] for lane > k (lanes <= k carry values nobody reads)
-        if (lane == k) diag = akk;
-        // column k of the factor goes to LDS in packed row order (L below the diagonal, 1/L_kk on it; the padded rows hold zeros):
-        // the trailing update reads L[j][k] back as a wave-uniform ds_read (a broadcast on the LDS pipe, no VALU slot), and
-        // k_mniw_trisolve gets the same layout
-        if (lane < MT && lane >= k) A[tl + k] = lane == k ? inv : lk;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const double bk = readlane_f64(b, k) * inv, wk = readlane_f64(w, k) * inv;
-        if (lane == k) {
-            b = bk;
-            w = wk;
-        } else if (lane > k) {
-            b = PGAS_FMA(-lk, bk, b);
-            w = PGAS_FMA(-lk, wk, w);
-        }
-        // A[lane][j] -= L[lane][k] L[j][k] (only lanes >= j are read later)
-        const double nlk = -lk;
+        if (k < M) {  // wave-uniform: columns M, M+1 (the right-hand sides' corner) and the padding are not pivots
+            const double inv = rsqrt_newton(readlane_f64(row[k], k));
+            const double lk = row[k] * inv;  // L[lane][k] for lane > k (lanes <= k carry values nobody reads)
+            // column k of the factor goes to LDS in packed row order (L below the diagonal, 1/L_kk on it)
+            if (lane < MT && lane >= k) A[tl + k] = lk;
+            if (lane == k) A[tl + k] = inv;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            // A[lane][j] -= L[lane][k] L[j][k] (only lanes >= j are read later)
+            const double nlk = -lk;
 #pragma unroll
-        for (int j0 = k + 1; j0 < MT; j0 += 8) {   // groups of 8 bound the registers the broadcast values occupy
-            double lj[8];
+            for (int j0 = k + 1; j0 < MT; j0 += 8) {   // groups of 8 bound the registers the broadcast values occupy
+                double lj[8];
 #pragma unroll
-            for (int j = j0; j < j0 + 8 && j < MT; ++j) lj[j - j0] = A[j * (j + 1) / 2 + k];   // eight reads in flight
+                for (int j = j0; j < j0 + 8 && j < MT; ++j) lj[j - j0] = A[j * (j + 1) / 2 + k];   // eight reads in flight
 #pragma unroll
-            for (int j = j0; j < j0 + 8 && j < MT; ++j) {
-                row[j] = PGAS_FMA(nlk, lj[j - j0], row[j]);
-                asm volatile("" : "+v"(row[j]));   // consume the broadcast here: otherwise every update of column j is deferred to iteration j
+                for (int j = j0; j < j0 + 8 && j < MT; ++j) {
+                    row[j] = PGAS_FMA(nlk, lj[j - j0], row[j]);
+                    asm volatile("" : "+v"(row[j]));   // consume the broadcast here: otherwise every update of column j is deferred to iteration j
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
-            __builtin_amdgcn_sched_barrier(0);
         }
-        CholColumn<MT, K + 1>::run(row, b, w, diag, bad, A, tl, lane);
+        CholColumn<MT, K + 1>::run(row, M, A, tl, lane);
     }
 };
 template <int MT>
 struct CholColumn<MT, MT> {
-    static __device__ __forceinline__ void run(double (&)[MT], double&, double&, double&, int&, double* __restrict__, int, int) {}
+    static __device__ __forceinline__ void run(double (&)[MT], int, double* __restrict__, int, int) {}
 };
 
+// Lfac_out (n, (M+2)(M+3)/2): the packed factor INCLUDING the two extra rows (row M = v, row M+1 = w = L^-1 eta0), for k_mniw_trisolve.
 template <int MT>
 __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double scale, const int32_t* __restrict__ anc, const double* __restrict__ P0,
                                                      const double* __restrict__ P1, const double* __restrict__ T0,
@@ -106,16 +102,13 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
                                                      const double* __restrict__ R1, const double* __restrict__ phi,
                                                      double* __restrict__ m_out, double* __restrict__ c_out,
                                                      double* __restrict__ q_out, double* __restrict__ logdet_out,
-                                                     double* __restrict__ Lfac_out, double* __restrict__ w_out, int32_t* __restrict__ fail_out) {
+                                                     double* __restrict__ Lfac_out, int32_t* __restrict__ fail_out) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (p >= n) return;  // whole wave leaves together; no workgroup barrier below
     const int64_t src = anc ? (int64_t)anc[p] : p;   // statistics of the resampled ancestor (src/Algorithm1.py:358-361)
-    // Only the lower triangle is needed (lane l uses columns <= l).  Row r is read by lanes 0..r, contiguous in memory, and parked
-    // in LDS in packed triangular order; then every lane picks up its own row.  Half the matrix never leaves HBM.
-    const int tri_n = M * (M + 1) / 2;
-    double* __restrict__ A = smem + (size_t)wave * (MT * (MT + 1) / 2);   // room for the MT padded rows (see the broadcast reads below)
+    double* __restrict__ A = smem + (size_t)wave * (MT * (MT + 1) / 2);
     const double* __restrict__ T1p = T1 + (size_t)src * M * M;
 #pragma unroll 6
     for (int r = 0; r < M; ++r) {
@@ -125,68 +118,71 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
             A[r * (r + 1) / 2 + lane] = v;
         }
     }
+    const int tM = M * (M + 1) / 2, tM1 = (M + 1) * (M + 2) / 2;   // starts of rows M and M+1
+    if (lane < M) {
+        double w = P0[lane] + scale * T0[(size_t)src * M + lane];
+        if (R0) w += R0[lane];
+        A[tM + lane] = phi ? phi[(size_t)p * M + lane] : 0.0;
+        A[tM1 + lane] = w;
+    } else if (lane == M) {   // the corner: (M,M), (M+1,M), (M+1,M+1)
+        A[tM + M] = 0.0;
+        A[tM1 + M] = 0.0;
+        A[tM1 + M + 1] = 0.0;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int tl = lane < MT ? lane * (lane + 1) / 2 : 0;
     double row[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
-        const bool have = lane < M && j <= lane;   // j <= lane < M
+        const bool have = lane < M + 2 && j <= lane;
         const double v = A[have ? tl + j : 0];
-        row[j] = have ? v : (j == lane ? 1.0 : 0.0);
+        row[j] = have ? v : 0.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    double b = 0.0, w = 0.0;  // right-hand sides: lane l holds phi_l and eta0_l
-    if (lane < M) {
-        w = P0[lane] + scale * T0[(size_t)src * M + lane];
-        if (R0) w += R0[lane];
-        if (phi) b = phi[(size_t)p * M + lane];
+    CholColumn<MT, 0>::run(row, M, A, tl, lane);
+    // rows M and M+1 now hold [v^T, -v.v] and [w^T, -w.v, -w.w]; put their tails (columns >= M) next to the factor in LDS
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+        if ((lane == M || lane == M + 1) && j >= M && j <= lane) A[tl + j] = row[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (Lfac_out) {  // hand the factor (with w in row M+1) to k_mniw_trisolve: the children of this particle reuse it
+        const int tri_out = (M + 2) * (M + 3) / 2;
+        double* __restrict__ dst = Lfac_out + (size_t)p * tri_out;
+        for (int e = lane; e < tri_out; e += 64) dst[e] = A[e];
     }
-    double diag = 1.0;  // pivot of this lane's column (before the square root)
-    int bad = 0;
-    CholColumn<MT, 0>::run(row, b, w, diag, bad, A, tl, lane);
-    if (Lfac_out) {  // hand the factor and w = L^-1 eta0 to k_mniw_trisolve (the children of this particle reuse them)
-        double* __restrict__ dst = Lfac_out + (size_t)p * tri_n;
-        for (int e = lane; e < tri_n; e += 64) dst[e] = A[e];
-        if (lane < M) w_out[(size_t)p * M + lane] = w;
-    }
-    const double mm = wave_sum_f64(lane < M ? w * b : 0.0);
-    const double cc = wave_sum_f64(lane < M ? b * b : 0.0);
-    const double qq = wave_sum_f64(lane < M ? w * w : 0.0);
-    const double ld = wave_sum_f64(lane < M ? pgas_log(diag) : 0.0);  // log det = sum log L_kk^2
+    const double dinv = lane < M ? A[tl + lane] : 1.0;                    // 1 / L_kk
+    const double ld = -2.0 * wave_sum_f64(lane < M ? pgas_log(dinv) : 0.0);  // log det eta1 = sum log L_kk^2
     if (lane == 0) {
-        if (m_out) m_out[p] = mm;
-        if (c_out) c_out[p] = cc;
-        if (q_out) q_out[p] = qq;
+        if (c_out) c_out[p] = -A[tM + M];
+        if (m_out) m_out[p] = -A[tM1 + M];
+        if (q_out) q_out[p] = -A[tM1 + M + 1];
         if (logdet_out) logdet_out[p] = ld;
-        if (bad && fail_out) atomicAdd(fail_out, 1);
+        if (!(ld - ld == 0.0) && fail_out) atomicAdd(fail_out, 1);   // a non-positive pivot leaves NaN / inf in the factor
     }
 }
 
 // Solve with a stored factor: v = L^-1 phi for the factor of particle anc[p] (written by k_mniw_solve), then
-// m = w . v and c = v . v with w = L^-1 eta0 of the same ancestor.  Same operation order as the substitution inside
-// k_mniw_solve, so the two kernels return identical numbers for identical matrices.  Streaming: 8 (M (M+1)/2 + 2 M) bytes per particle.
+// m = w . v and c = v . v with w = L^-1 eta0 of the same ancestor (row M+1 of the stored triangle).
+// Streaming: 8 ((M+2)(M+3)/2 + M) bytes per particle.
 __global__ __launch_bounds__(256) void k_mniw_trisolve(int64_t n, int M, const int32_t* __restrict__ anc, const double* __restrict__ Lfac,
-                                                        const double* __restrict__ wvec, const double* __restrict__ phi,
-                                                        double* __restrict__ m_out, double* __restrict__ c_out) {
+                                                        const double* __restrict__ phi, double* __restrict__ m_out, double* __restrict__ c_out) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
     if (p >= n) return;
     const int64_t src = anc ? (int64_t)anc[p] : p;
-    const int tri_n = M * (M + 1) / 2;
+    const int tri_n = (M + 2) * (M + 3) / 2;
     double* __restrict__ A = smem + (size_t)wave * tri_n;
     const double* __restrict__ Ls = Lfac + (size_t)src * tri_n;
     for (int e = lane; e < tri_n; e += 64) A[e] = Ls[e];
-    double b = 0.0, w = 0.0;
-    if (lane < M) {
-        b = phi[(size_t)p * M + lane];
-        w = wvec[(size_t)src * M + lane];
-    }
+    double b = lane < M ? phi[(size_t)p * M + lane] : 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int tl = lane < M ? lane * (lane + 1) / 2 : 0;
+    const double w = lane < M ? A[(M + 1) * (M + 2) / 2 + lane] : 0.0;
     const double dinv = lane < M ? A[tl + lane] : 1.0;
     for (int k = 0; k < M; ++k) {
         const double bk = readlane_f64(b, k) * readlane_f64(dinv, k);
@@ -209,7 +205,7 @@ __global__ __launch_bounds__(256) void k_stats_gather_update(int64_t n, int M, d
                                                               const double* __restrict__ phi, const double* __restrict__ xi,
                                                               double* __restrict__ T0o, double* __restrict__ T1o, double* __restrict__ T2o,
                                                               double* __restrict__ T3o) {
-    __shared__ double sphi[PG_MN_MAXM * 2];
+    __shared__ double sphi[128];
     const int64_t p = blockIdx.x;
     const int64_t a = anc ? (int64_t)anc[p] : p;
     const int tid = threadIdx.x;
@@ -269,8 +265,16 @@ __global__ __launch_bounds__(256) void k_weighted_stats_final(int nchunk, int M,
     const int ncol = M * M + M + 2, mm = M * M;
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= ncol) return;
-    double acc = 0.0;
-    for (int c = 0; c < nchunk; ++c) acc += partial[(size_t)c * ncol + col];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four chains in a fixed interleaving: deterministic, and the loads overlap
+    int c = 0;
+    for (; c + 3 < nchunk; c += 4) {
+        a0 += partial[(size_t)c * ncol + col];
+        a1 += partial[(size_t)(c + 1) * ncol + col];
+        a2 += partial[(size_t)(c + 2) * ncol + col];
+        a3 += partial[(size_t)(c + 3) * ncol + col];
+    }
+    for (; c < nchunk; ++c) a0 += partial[(size_t)c * ncol + col];
+    const double acc = (a0 + a1) + (a2 + a3);
     if (col < mm) S1[col] = acc;
     else if (col < mm + M) S0[col - mm] = acc;
     else if (col == mm + M) S2[0] = acc;

@@ -289,7 +289,7 @@ class _SlipAngleBasis:
 def vehicle_marginal(T=1500, seed=12345678, M=20):
     """src/Vehicle.py:14-292: lateral vehicle dynamics, the two tyre friction curves mu_y(alpha_f), mu_y(alpha_r) are the latent
     functions (two scalar interface variables).  M = 20 is the reference's basis size; BASELINE.json configs[2] asks for a
-    larger set (the device kernels take M <= 64)."""
+    larger set (the device kernels take M <= 62)."""
     m, I_zz, l_f, l_r, g, mu_x = 1720.0, 1827.5, 1.16, 1.47, 9.81, 0.9    # :17-22
     dt = 0.02                                                              # :183
     pv = vehicle_pgas(T=T, seed=seed, M=27)                                # same simulated states and inputs (:199-257)

@@ -32,20 +32,21 @@ int pgas_m_rng_student_t(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t
                          double* out_dev, void* stream_handle);
 
 /* Per particle p, with s = anc[p] (anc NULL: s = p): eta0 = P0 + scale T0[s] (+ R0), eta1 = P1 + scale T1[s] (+ R1)
- * (M <= 64, eta1 symmetric positive definite);
+ * (M <= 62, eta1 symmetric positive definite);
  *   m[p] = eta0^T eta1^-1 phi[p],  c[p] = phi[p]^T eta1^-1 phi[p],  q[p] = eta0^T eta1^-1 eta0,  logdet[p] = log det eta1.
  * R0/R1 (the reference trajectory's statistics, src/Algorithm3.py:96-101), phi and every output may be NULL.
- * Lfac_dev (n, M (M+1)/2) and w_dev (n, M), given together or both NULL, receive the packed Cholesky factor of eta1 (rows of L,
- * 1/L_kk on the diagonal) and w = L^-1 eta0 for pgas_m_mniw_trisolve: the children of a resampled particle share its matrix
- * (src/Algorithm1.py:358-361), so it is factorised once per step, before resampling, not once more per child.
+ * Lfac_dev (n, (M+2)(M+3)/2), optional, receives the packed Cholesky factor for pgas_m_mniw_trisolve: rows of L with 1/L_kk on the
+ * diagonal, followed by the two right-hand-side rows the kernel eliminates along with the matrix (row M = L^-1 phi, row M+1 =
+ * w = L^-1 eta0).  The children of a resampled particle share its matrix (src/Algorithm1.py:358-361), so it is factorised once
+ * per step, before resampling, not once more per child.
  * Asynchronous; a matrix that is not positive definite is counted on the device and reported by pgas_m_check. */
 int pgas_m_mniw_solve(pgas_ctx* ctx, int64_t n, int32_t M, double scale, const int32_t* anc_dev, const double* P0_dev, const double* P1_dev,
                       const double* T0_dev, const double* T1_dev, const double* R0_dev, const double* R1_dev, const double* phi_dev,
-                      double* m_dev, double* c_dev, double* q_dev, double* logdet_dev, double* Lfac_dev, double* w_dev, void* stream_handle);
+                      double* m_dev, double* c_dev, double* q_dev, double* logdet_dev, double* Lfac_dev, void* stream_handle);
 
-/* With the factor and w stored by pgas_m_mniw_solve: m[p] = w[s] . v, c[p] = v . v, v = L[s]^-1 phi[p], s = anc[p] (NULL: p). */
-int pgas_m_mniw_trisolve(pgas_ctx* ctx, int64_t n, int32_t M, const int32_t* anc_dev, const double* Lfac_dev, const double* w_dev,
-                         const double* phi_dev, double* m_dev, double* c_dev, void* stream_handle);
+/* With the factor stored by pgas_m_mniw_solve: m[p] = w[s] . v, c[p] = v . v, v = L[s]^-1 phi[p], s = anc[p] (NULL: p). */
+int pgas_m_mniw_trisolve(pgas_ctx* ctx, int64_t n, int32_t M, const int32_t* anc_dev, const double* Lfac_dev, const double* phi_dev,
+                         double* m_dev, double* c_dev, void* stream_handle);
 
 /* Synchronises the stream; PGAS_E_STATE if any pgas_m_mniw_solve since the last check met a matrix that was not positive
  * definite (its outputs are NaN). */

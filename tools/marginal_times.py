@@ -47,7 +47,7 @@ for N in [int(a) for a in (sys.argv[1:] or ["200", "16384", "131072", "1048576"]
     w = torch.softmax(l, 0)
     us_wsum = ev(lambda: alg._weighted(ss[0], w))
     bytes_stats = 8.0 * (M * M + M + 2) * N
-    print(f"{pb.name} M={M} x{len(iv)} N={N:8d}: step {dt*1e3:8.3f} ms = {N/dt:.3e} particle-steps/s | k_mniw_solve+store {us_fac:9.1f} us | k_mniw_trisolve {us_tri:8.1f} us ({8.0*(M*(M+1)/2+2*M)*N/us_tri/1e3:7.1f} GB/s) | k_mniw_solve {us_solve:9.1f} us ({bytes_stats/us_solve/1e3:7.1f} GB/s read) | "
+    print(f"{pb.name} M={M} x{len(iv)} N={N:8d}: step {dt*1e3:8.3f} ms = {N/dt:.3e} particle-steps/s | k_mniw_solve+store {us_fac:9.1f} us | k_mniw_trisolve {us_tri:8.1f} us ({8.0*((M+2)*(M+3)/2+M)*N/us_tri/1e3:7.1f} GB/s) | k_mniw_solve {us_solve:9.1f} us ({bytes_stats/us_solve/1e3:7.1f} GB/s read) | "
           f"k_stats_gather_update {us_upd:9.1f} us ({2*bytes_stats/us_upd/1e3:7.1f} GB/s r+w) | resample {us_rs:7.1f} us | k_weighted_stats {us_wsum:9.1f} us ({bytes_stats/us_wsum/1e3:7.1f} GB/s read)", flush=True)
     del alg, ss, st, iv, sst, lw, anc
     torch.cuda.empty_cache()
