@@ -74,6 +74,7 @@ struct pgas_ctx {
     int corrected = 0;          // PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE: propagate from the resampled ancestors (quirk Q1 removed)
     double* aux_buf = nullptr;  // (N, nx) transition means of the current step, corrected mode only
     int32_t* d_fail = nullptr;  // failure counter of pgas_m_mniw_solve
+    int mniw_valu = 0;          // PGAS_OPT_MNIW_VALU: 1 = column-by-column VALU factorisation instead of the MFMA-blocked one
     double* ws_partial = nullptr;  // per-chunk partial sums of pgas_m_weighted_stats
     size_t ws_bytes = 0;
     init_fn init = nullptr;
@@ -601,6 +602,10 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         c->prop_lds = (int)value;
         return PGAS_OK;
     }
+    if (option == PGAS_OPT_MNIW_VALU) {
+        c->mniw_valu = value ? 1 : 0;
+        return PGAS_OK;
+    }
     if (option == PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE) {
         if (value && c->sharded) FAIL(c, PGAS_E_STATE, "pgas_set_option: the corrected mode is not available on a sharded context");
         c->corrected = value ? 1 : 0;
@@ -892,12 +897,23 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
         HIPCHK(c, hipMalloc(&c->d_fail, sizeof(int32_t)));
         HIPCHK(c, hipMemsetAsync(c->d_fail, 0, sizeof(int32_t), st));
     }
-    const int MT = M <= 22 ? 24 : M <= 30 ? 32 : M <= 42 ? 44 : M <= 46 ? 48 : 64;   // rows: M + 2 (the right-hand sides ride along)
-    const int waves = MT == 64 ? 2 : 4;   // LDS: waves x MT (MT+1)/2 doubles <= 64 KB
-    const dim3 grd((unsigned)((n + waves - 1) / waves)), blk(64 * waves);
-    auto kern = MT == 24 ? k_mniw_solve<24> : MT == 32 ? k_mniw_solve<32> : MT == 44 ? k_mniw_solve<44> : MT == 48 ? k_mniw_solve<48> : k_mniw_solve<64>;
-    hipLaunchKernelGGL(kern, grd, blk, (size_t)waves * (MT * (MT + 1) / 2) * sizeof(double), st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q,
-                       logdet, Lfac, c->d_fail);
+    if (c->mniw_valu) {
+        const int MT = M <= 22 ? 24 : M <= 30 ? 32 : M <= 42 ? 44 : M <= 46 ? 48 : 64;   // rows: M + 2 (the right-hand sides ride along)
+        const int waves = MT == 64 ? 2 : 4;   // LDS: waves x MT (MT+1)/2 doubles <= 64 KB
+        const dim3 grd((unsigned)((n + waves - 1) / waves)), blk(64 * waves);
+        auto kern = MT == 24 ? k_mniw_solve<24> : MT == 32 ? k_mniw_solve<32> : MT == 44 ? k_mniw_solve<44> : MT == 48 ? k_mniw_solve<48> : k_mniw_solve<64>;
+        hipLaunchKernelGGL(kern, grd, blk, (size_t)waves * (MT * (MT + 1) / 2) * sizeof(double), st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q,
+                           logdet, Lfac, c->d_fail);
+    } else {
+        // default: panels of four columns, trailing update on the f64 matrix cores
+        const int NT = (M + 2 + 15) / 16;
+        const int R = 16 * NT, perw = 4 * R + R * (R + 1) / 2;
+        const int waves = NT == 4 ? 3 : 4;   // LDS: waves x perw doubles <= 64 KB
+        const dim3 grd((unsigned)((n + waves - 1) / waves)), blk(64 * waves);
+        auto kern = NT == 1 ? k_mniw_solve_mfma<1> : NT == 2 ? k_mniw_solve_mfma<2> : NT == 3 ? k_mniw_solve_mfma<3> : k_mniw_solve_mfma<4>;
+        hipLaunchKernelGGL(kern, grd, blk, (size_t)waves * perw * sizeof(double), st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q, logdet, Lfac,
+                           c->d_fail);
+    }
     KCHK(c, "k_mniw_solve");
     return PGAS_OK;
 }

@@ -164,6 +164,159 @@ __global__ __launch_bounds__(256) void k_mniw_solve(int64_t n, int M, double sca
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_mniw_solve_mfma: the same factorisation, blocked by panels of four columns, with the trailing update
+//     A22 -= L21 L21^T      (a rank-4 update of every remaining 16 x 16 tile)
+// on v_mfma_f64_16x16x4_f64.  The (M+2)-row augmented matrix (see k_mniw_solve) lives in the MFMA accumulator layout,
+// lower tiles only: tile (tr, tc), register i of lane l = element (16 tr + (l>>4) + 4 i, 16 tc + (l&15)).  Per panel:
+//   (a) the four panel columns go from the accumulators to LDS,  (b) come back with lane = row,
+//   (c) are factorised in registers (pivot broadcast by v_readlane, 1/sqrt by v_rsq_f64 + Newton),
+//   (d) the scaled columns go to LDS as the MFMA operand image P[k][row] (rows above the trailing block and non-pivot
+//       columns zeroed) and, packed, as the output factor,  (e) each lane picks up its A/B operand element
+//       P[l>>4][16 r + (l&15)] per tile row,  (f) one MFMA per remaining tile.
+// c, q and m (= the Schur complement of the two right-hand-side rows) are accumulated column by column on lanes M, M+1.
+// ------------------------------------------------------------------------------------------
+typedef double pg_mf4 __attribute__((ext_vector_type(4)));
+__host__ __device__ constexpr int pg_tile_id(int tr, int tc) { return tr * (tr + 1) / 2 + tc; }
+
+template <int NT, int P>
+struct CholPanel {
+    static __device__ __forceinline__ void run(pg_mf4 (&acc)[NT * (NT + 1) / 2], int M, double* __restrict__ colbuf, double* __restrict__ Lpack,
+                                               int lane, double& dinv, double& nrm, double& crs) {
+        constexpr int R = 16 * NT, k0 = 4 * P, tc = k0 / 16, c0 = k0 % 16, tcur = (k0 + 4) / 16;
+        if (k0 < M) {  // wave-uniform: this panel holds at least one pivot column
+            const int lc = (lane & 15) - c0;  // which panel column this lane's accumulator column is, if 0..3
+            if (lc >= 0 && lc < 4) {
+#pragma unroll
+                for (int tr = tc; tr < NT; ++tr)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) colbuf[lc * R + 16 * tr + (lane >> 4) + 4 * i] = acc[pg_tile_id(tr, tc)][i];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            double a[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) a[c] = colbuf[c * R + (lane < R ? lane : 0)];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                constexpr int kbase = k0;
+                const int k = kbase + c;
+                if (k < M) {  // wave-uniform: columns M, M+1 (right-hand sides) and the padding are not pivots
+                    const double inv = rsqrt_newton(readlane_f64(a[c], k));
+                    a[c] = a[c] * inv;  // L[lane][k] for lane > k
+                    if (lane == k) dinv = inv;
+#pragma unroll
+                    for (int c2 = c + 1; c2 < 4; ++c2) a[c2] = PGAS_FMA(-a[c], readlane_f64(a[c], kbase + c2), a[c2]);
+                    nrm = PGAS_FMA(a[c], a[c], nrm);                     // lane M: v.v, lane M+1: w.w
+                    crs = PGAS_FMA(a[c], readlane_f64(a[c], M), crs);    // lane M+1: w.v
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int k = k0 + c;
+                const bool piv = k < M;
+                if (lane < R) colbuf[c * R + lane] = (piv && lane >= k0 + 4) ? a[c] : 0.0;
+                if (piv && lane >= k && lane < M + 2) Lpack[lane * (lane + 1) / 2 + k] = lane == k ? dinv : a[c];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (tcur < NT) {
+                double op[NT];
+#pragma unroll
+                for (int r = tcur; r < NT; ++r) op[r] = colbuf[(lane >> 4) * R + 16 * r + (lane & 15)];
+#pragma unroll
+                for (int tr = tcur; tr < NT; ++tr)
+#pragma unroll
+                    for (int t2 = tcur; t2 <= tr; ++t2)
+                        acc[pg_tile_id(tr, t2)] = __builtin_amdgcn_mfma_f64_16x16x4f64(-op[tr], op[t2], acc[pg_tile_id(tr, t2)], 0, 0, 0);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+        CholPanel<NT, P + 1>::run(acc, M, colbuf, Lpack, lane, dinv, nrm, crs);
+    }
+};
+template <int NT>
+struct CholPanel<NT, 4 * NT> {
+    static __device__ __forceinline__ void run(pg_mf4 (&)[NT * (NT + 1) / 2], int, double* __restrict__, double* __restrict__, int, double&, double&,
+                                               double&) {}
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void k_mniw_solve_mfma(int64_t n, int M, double scale, const int32_t* __restrict__ anc, const double* __restrict__ P0,
+                                                          const double* __restrict__ P1, const double* __restrict__ T0,
+                                                          const double* __restrict__ T1, const double* __restrict__ R0,
+                                                          const double* __restrict__ R1, const double* __restrict__ phi,
+                                                          double* __restrict__ m_out, double* __restrict__ c_out,
+                                                          double* __restrict__ q_out, double* __restrict__ logdet_out,
+                                                          double* __restrict__ Lfac_out, int32_t* __restrict__ fail_out) {
+    extern __shared__ double smem[];
+    constexpr int R = 16 * NT, PERW = 4 * R + R * (R + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t p = (int64_t)blockIdx.x * (blockDim.x >> 6) + wave;
+    if (p >= n) return;  // whole wave leaves together; no workgroup barrier below
+    const int64_t src = anc ? (int64_t)anc[p] : p;
+    double* __restrict__ colbuf = smem + (size_t)wave * PERW;
+    double* __restrict__ Lpack = colbuf + 4 * R;
+    const double* __restrict__ T1p = T1 + (size_t)src * M * M;
+    pg_mf4 acc[NT * (NT + 1) / 2];
+    // Branch-free loader straight into the accumulator layout: every element is read from a clamped (always valid) address and
+    // then selected, so all loads of a matrix are in flight together (staging rows through LDS first, as k_mniw_solve does,
+    // issues fewer instructions but measured 30 % slower here: its row loop serialises the memory latency).
+    // Column values of the two right-hand-side rows first (one per tile column and lane) ...
+    const int lr = lane >> 4, lcol = lane & 15;
+    double phic[NT], etac[NT];
+#pragma unroll
+    for (int t2 = 0; t2 < NT; ++t2) {
+        const int col = 16 * t2 + lcol, cc = col < M ? col : 0;
+        double e = P0[cc] + scale * T0[(size_t)src * M + cc];
+        if (R0) e += R0[cc];
+        phic[t2] = phi ? phi[(size_t)p * M + cc] : 0.0;
+        etac[t2] = e;
+    }
+    // ... then the lower tiles of eta1 = P1 + scale T1 (+ R1)
+#pragma unroll
+    for (int tr = 0; tr < NT; ++tr)
+#pragma unroll
+        for (int t2 = 0; t2 <= tr; ++t2)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = 16 * tr + lr + 4 * i, col = 16 * t2 + lcol;
+                const bool inmat = row < M && col <= row;
+                const int e = inmat ? row * M + col : 0;
+                double v = P1[e] + scale * T1p[e];
+                if (R1) v += R1[e];
+                const double rhs = row == M ? phic[t2] : etac[t2];
+                acc[pg_tile_id(tr, t2)][i] = inmat ? v : ((col < M && (row == M || row == M + 1)) ? rhs : 0.0);
+            }
+    double dinv = 1.0, nrm = 0.0, crs = 0.0;
+    CholPanel<NT, 0>::run(acc, M, colbuf, Lpack, lane, dinv, nrm, crs);
+    if (lane == M) {  // the corner of the packed output (not read by k_mniw_trisolve)
+        const int tM = M * (M + 1) / 2, tM1 = (M + 1) * (M + 2) / 2;
+        Lpack[tM + M] = 0.0;
+        Lpack[tM1 + M] = 0.0;
+        Lpack[tM1 + M + 1] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (Lfac_out) {
+        const int tri_out = (M + 2) * (M + 3) / 2;
+        double* __restrict__ dst = Lfac_out + (size_t)p * tri_out;
+        for (int e = lane; e < tri_out; e += 64) dst[e] = Lpack[e];
+    }
+    const double ld = -2.0 * wave_sum_f64(lane < M ? pgas_log(dinv) : 0.0);
+    const double cc = readlane_f64(nrm, M), qq = readlane_f64(nrm, M + 1), mm = readlane_f64(crs, M + 1);
+    if (lane == 0) {
+        if (c_out) c_out[p] = cc;
+        if (m_out) m_out[p] = mm;
+        if (q_out) q_out[p] = qq;
+        if (logdet_out) logdet_out[p] = ld;
+        if (!(ld - ld == 0.0) && fail_out) atomicAdd(fail_out, 1);
+    }
+}
+
 // Solve with a stored factor: v = L^-1 phi for the factor of particle anc[p] (written by k_mniw_solve), then
 // m = w . v and c = v . v with w = L^-1 eta0 of the same ancestor (row M+1 of the stored triangle).
 // Streaming: 8 ((M+2)(M+3)/2 + M) bytes per particle.

@@ -139,6 +139,7 @@ int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample
  * (and as src/Algorithm1.py:286-292 does).  Same random numbers, same weight formula; the step becomes a serial chain of
  * three launches.  Default 0 = reproduce the reference. */
 #define PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE 5
+#define PGAS_OPT_MNIW_VALU 6 /* 1: pgas_m_mniw_solve factorises column by column on the VALU instead of in MFMA-blocked panels (test knob) */
 int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
 
 /* Free functions of src/Filtering.py on the device.  systematic_SISR(key, w) (:6-37): u = the uniform the reference draws

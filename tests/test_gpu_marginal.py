@@ -33,9 +33,19 @@ def test_rng_kernels_bit_exact():
     assert ops.uniform(SEED, 18, 7) == canon.uniform(SEED, 18, 7)
 
 
-@pytest.mark.parametrize("N,M", [(300, 41), (1000, 20), (257, 62), (500, 46), (300, 30), (64, 1)])
-def test_mniw_solve_against_torch(N, M):
+@pytest.mark.parametrize("valu", [0, 1])
+@pytest.mark.parametrize("N,M", [(300, 41), (1000, 20), (257, 62), (500, 46), (300, 30), (70, 14), (64, 1), (130, 5)])
+def test_mniw_solve_against_torch(N, M, valu):
+    """Both factorisation kernels: the MFMA-blocked default and the column-by-column VALU one (PGAS_OPT_MNIW_VALU)."""
     ops = _ops(N)
+    ops.eng.set_option(6, valu)
+    try:
+        _check_mniw_solve(ops, N, M)
+    finally:
+        ops.eng.set_option(6, 0)
+
+
+def _check_mniw_solve(ops, N, M):
     g = torch.Generator(device="cpu").manual_seed(3)
     dev = ops.device
     B = torch.randn(N, M, 3, generator=g, dtype=torch.float64)

@@ -22,6 +22,7 @@ for N in [int(a) for a in (sys.argv[1:] or ["200", "16384", "131072", "1048576"]
     alg = pgas_amd.Algorithm1(N_samples=N, observations=pb.observations, inputs=pb.inputs, SSM=ssm, forgetting_factor=pb.forgetting_factor,
                               init_state_mean=pb.init_state_mean, init_state_cov=pb.init_state_cov, init_int_var_mean=pb.init_int_var_mean,
                               init_int_var_cov=pb.init_int_var_cov, GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn())
+    alg.ops.eng.set_option(6, int(os.environ.get('MNIW_VALU', '0')))
     rand = alg._rand(1)
     st, iv, sst, lw, anc, ss = alg._init_algorithm(rand)
     x, l, v = st[0], lw[0], [iv[i][0] for i in range(len(iv))]
