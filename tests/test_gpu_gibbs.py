@@ -11,6 +11,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _driver(name="Toy_Example_Simulation"):
+    import sys
+
+    ex = os.path.join(ROOT, "examples")
+    if ex not in sys.path:
+        sys.path.insert(0, ex)   # the drivers share examples/_marginal_driver.py
     spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "examples", name + ".py"))
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
@@ -45,9 +50,16 @@ def test_toy_posterior_mean_approaches_true_function(corrected):
 def test_emps_driver_fields_and_tracking():
     """examples/EMPS_Simulation.py (PGAS part of the reference driver, synthetic data): field names and shapes of the .mat
     dictionary (EMPS_Simulation.py:128-160) and a sanity bound on the sampled positions (measurement noise std 1e-2)."""
-    res = _driver("EMPS_Simulation").run(iterations=4, particles=256, steps=300)
+    drv = _driver("EMPS_Simulation")
+    res = drv.run(iterations=4, particles=256, steps=300)
+    ppb = res.pop("_pb")
     assert res["offline_Sigma_X_PGAS"].shape == (300, 4, 2) and res["offline_log_likelihood_PGAS"].shape == (300, 4)
-    assert res["PGAS_mean"].shape == (2, 729) and res["PGAS_T1"].shape == (729, 729) and res["PGAS_T3"] == res["prior_T3"] + 299
+    assert res["PGAS_mean"].shape == (2, 729) and res["PGAS_T1"].shape == (729, 729) and res["PGAS_T3"] == res["prior_T3_PGAS"] + 299
+    marg, mpb = drv.run_marginal(iterations=3, particles=200, steps=300, log=lambda *_: None)
+    assert marg["online_Sigma_F"].shape == (300, 200, 1) and marg["offline_T1"].shape == (3, 9, 9) and marg["offline_mean"].shape == (1, 9)
+    assert np.isfinite(marg["online_Sigma_X"]).all() and np.isfinite(marg["offline_Sigma_X"]).all()
+    r_alg2, r_pgas = drv.validation_rmse(marg["offline_mean"], res["PGAS_mean"], mpb, ppb, steps=120)
+    assert np.isfinite(r_alg2) and np.isfinite(r_pgas)
     assert np.isfinite(res["offline_Sigma_X_PGAS"]).all()
     err = res["offline_Sigma_X_PGAS"][:, -1, 0] - res["X"][:, 0]
     assert np.sqrt(np.mean(err ** 2)) < 0.05
@@ -70,3 +82,20 @@ def test_smo_driver_learns_the_spring_damper_force():
     rmse, rms_true = drv.posterior_force_rmse(res, "online")
     print("online F_sd RMSE", rmse, "RMS of the true force", rms_true)
     assert rmse < 0.6 * rms_true
+
+
+def test_vehicle_driver_two_latent_functions():
+    """examples/VehicleSimulation_Simulation.py (shortened): the reference's .mat fields for both tyres, finite outputs, and the
+    filtered yaw rate follows the simulated truth."""
+    drv = _driver("VehicleSimulation_Simulation")
+    res = drv.run(particles=200, iterations=3, steps=300, log=lambda *_: None)
+    T, N, K = 300, 200, 3
+    for s in "fr":
+        assert res[f"online_Sigma_mu_{s}"].shape == (T, N, 1) and res[f"online_T1_{s}"].shape == (T, 20, 20)
+        assert res[f"offline_Sigma_mu_{s}"].shape == (T, K, 1) and res[f"offline_T0_{s}"].shape == (K, 20, 1)
+        assert res[f"online_Sigma_alpha_{s}"].shape == (T, N) and res[f"offline_Sigma_alpha_{s}"].shape == (T, K)
+    assert res["online_Sigma_Y"].shape == (T, N, 2) and res["offline_Sigma_X"].shape == (T, K, 2)
+    for k in ("online_Sigma_X", "online_Sigma_mu_f", "online_Sigma_mu_r", "offline_Sigma_X", "offline_log_likelihood", "online_T1_r"):
+        assert np.isfinite(res[k]).all(), k
+    xm = (res["online_Sigma_X"][:, :, 0] * res["online_weights"]).sum(axis=1)
+    assert np.sqrt(np.mean((xm[20:] - res["X"][20:, 0]) ** 2)) < 0.05
