@@ -189,3 +189,29 @@ def test_algorithm2_runs_and_returns_reference_shapes():
     assert SS[0][0].shape == (K, 40, 1) and SS[0][1].shape == (K, 40, 40) and SS[0][3].shape == (K,)
     assert torch.isfinite(X).all() and torch.isfinite(LL).all() and torch.all(SS[0][3] == T)
     assert torch.allclose(X[:, 0, 0], torch.as_tensor(pb.X_true[:, 0], device=X.device))
+
+
+@pytest.mark.parametrize("name", ["smo", "toy", "vehicle"])
+def test_device_matches_committed_vectors(name):
+    """The device path against tests/golden/marginal_runs.json (vectors of the NumPy restatement, tools/make_golden.py)."""
+    import json
+    import os
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "marginal_runs.json")))[name]
+    pb = _problem(name, T=g["T"])
+    N = g["N"]
+    got = _device_alg(pb, N)(g["seed"])
+    assert np.array_equal(got[4].cpu().numpy(), np.array(g["alg1_ancestors"]))
+    _close(got[0][-1].reshape(-1), np.array(g["alg1_state_last"]), "state (last step)")
+    _close(got[3][-1], np.array(g["alg1_weights_last"]), "weights (last step)", tol=1e-7)
+    for i in range(len(pb.basis)):
+        _close(got[1][i][-1].reshape(-1), np.array(g["alg1_int_var_last"][i]), f"int_var[{i}] (last step)")
+    from oracle import marginal_numpy as mo2
+
+    a3 = marginal_oracle(pb, N, "Algorithm3")
+    ref_stats = mo2.trajectory_stats(a3, pb.X_true, list(pb.int_var_true))
+    gt, gi, gtr = _device_alg(pb, N, "Algorithm3")(g["seed"], pb.X_true, list(pb.int_var_true), ref_stats, return_traces=True)
+    assert np.array_equal(gtr["ancestor_trace"].cpu().numpy(), np.array(g["alg3_ancestors"])) and gtr["idx"] == g["alg3_idx"]
+    _close(gt.reshape(-1), np.array(g["alg3_state_traj"]), "Algorithm3 state trajectory")
+    for i in range(len(pb.basis)):
+        _close(gi[i].reshape(-1), np.array(g["alg3_int_var_traj"][i]), f"Algorithm3 int_var trajectory {i}")

@@ -82,3 +82,21 @@ def test_algorithm3_keeps_the_reference_and_consumes_its_statistics():
     phi = alg.basis_fcn[0](ref_x[1][None], alg.inputs[1])[0]
     assert np.allclose(out[5][0][1], rs[0][1] - np.outer(phi, phi)) and np.isclose(out[5][0][3], rs[0][3] - 1)
     assert np.array_equal(out[1][-1], ref_x[1]) and out[2][0][-1, 0] == ref_iv[0][1]
+
+
+@pytest.mark.parametrize("name", ["smo", "toy", "vehicle"])
+def test_restatement_matches_committed_vectors(name):
+    """tests/golden/marginal_runs.json (tools/make_golden.py): regression vectors of the restatement on the canonical Philox streams."""
+    import json
+    import os
+
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "marginal_runs.json")))[name]
+    pb = {"smo": experiments.smo_marginal, "toy": experiments.toy_marginal, "vehicle": experiments.vehicle_marginal}[name](T=g["T"])
+    N = g["N"]
+    o1 = marginal_oracle(pb, N)(CanonRand(g["seed"], N))
+    assert np.array_equal(o1[4], np.array(g["alg1_ancestors"]))
+    assert np.allclose(o1[0][-1].reshape(-1), g["alg1_state_last"], rtol=1e-10, atol=1e-13)
+    assert np.allclose(o1[3][-1], g["alg1_weights_last"], rtol=1e-8, atol=1e-14)
+    for i in range(len(pb.basis)):
+        assert np.allclose(o1[1][i][-1].reshape(-1), g["alg1_int_var_last"][i], rtol=1e-9, atol=1e-12)
+        assert np.allclose(np.diag(o1[2][i][1][-1]), g["alg1_T1_trace_diag_last"][i], rtol=1e-9, atol=1e-13)

@@ -52,6 +52,32 @@ def main():
             "logw_last_hex": [float(v).hex() for v in lw[:8]],
         }
     json.dump(out, open(os.path.join(GOLD, "canon_sweeps.json"), "w"), indent=1)
+
+    # (3) regression vectors of the NumPy restatement of the marginalised family (oracle/marginal_numpy.py) on the canonical
+    #     Philox streams: tiny Algorithm1 / Algorithm3 runs, so that a change of the restatement, of the problem definitions or of
+    #     the random-number streams is caught on CPU, and the GPU tests have a committed target besides the live oracle.
+    from common import CanonRand, marginal_oracle
+    from oracle import marginal_numpy as mo
+
+    marg = {}
+    for name, mk, N in (("smo", experiments.smo_marginal, 48), ("toy", experiments.toy_marginal, 40), ("vehicle", experiments.vehicle_marginal, 36)):
+        pb = mk(T=6)
+        o1 = marginal_oracle(pb, N)(CanonRand(12345678, N))
+        a3 = marginal_oracle(pb, N, "Algorithm3")
+        ref_stats = mo.trajectory_stats(a3, pb.X_true, list(pb.int_var_true))
+        traj, ivt, tr = a3(CanonRand(12345678, N), pb.X_true, list(pb.int_var_true), ref_stats)
+        marg[name] = {
+            "N": N, "T": pb.T, "seed": 12345678,
+            "alg1_ancestors": o1[4].tolist(),
+            "alg1_state_last": o1[0][-1].reshape(-1).tolist(),
+            "alg1_int_var_last": [v[-1].reshape(-1).tolist() for v in o1[1]],
+            "alg1_weights_last": o1[3][-1].tolist(),
+            "alg1_T1_trace_diag_last": [np.diag(s[1][-1]).tolist() for s in o1[2]],
+            "alg3_ancestors": tr["ancestor_trace"].tolist(), "alg3_idx": int(tr["idx"]),
+            "alg3_state_traj": np.asarray(traj).reshape(-1).tolist(),
+            "alg3_int_var_traj": [np.asarray(v).reshape(-1).tolist() for v in ivt],
+        }
+    json.dump(marg, open(os.path.join(GOLD, "marginal_runs.json"), "w"), indent=1)
     print("golden fixtures written to", GOLD)
 
 
