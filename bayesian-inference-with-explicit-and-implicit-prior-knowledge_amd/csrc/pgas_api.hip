@@ -19,6 +19,9 @@
 #ifndef PG_W28
 #define PG_W28 2
 #endif
+#ifndef PG_P3
+#define PG_P3 2   // particles per basis pass of the 3-D variants
+#endif
 namespace {
 
 thread_local std::string g_create_error;
@@ -57,7 +60,7 @@ bool pick_variant(int nx, int D, int jin_needed, Variant* v, int* JP) {
         else *v = jp == 8 ? make_variant<1, 3, 8, 2, 2>() : jp == 12 ? make_variant<1, 3, 12, 2, 2>() : make_variant<1, 3, 16, 2, 2>();
     } else {
         if (D == 2) *v = jp == 8 ? make_variant<2, 2, 8, 2, PG_W28>() : jp == 12 ? make_variant<2, 2, 12, 2, 2>() : make_variant<2, 2, 16, 2, 2>();
-        else *v = jp == 8 ? make_variant<2, 3, 8, 2, 2>() : jp == 12 ? make_variant<2, 3, 12, 2, 2>() : make_variant<2, 3, 16, 2, 2>();
+        else *v = jp == 8 ? make_variant<2, 3, 8, PG_P3, 2>() : jp == 12 ? make_variant<2, 3, 12, PG_P3, 2>() : make_variant<2, 3, 16, PG_P3, 2>();
     }
     return true;
 }
