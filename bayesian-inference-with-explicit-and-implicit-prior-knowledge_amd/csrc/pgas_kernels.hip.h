@@ -510,9 +510,10 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
             double m = sm.red[w][0];
 #pragma unroll
             for (int v = 1; v < PG_BLK / 64; ++v) m = __builtin_fmax(m, sm.red[w][v]);
-            mx[w] = m;
+            const double kref = pgas_seg_ref(m);  // power-of-two reference of the segment (include/pgas_canon.h)
+            mx[w] = kref;
 #pragma unroll
-            for (int r = 0; r < PG_PPT; ++r) arg[w * PG_PPT + r] = lw[w][r] - m;
+            for (int r = 0; r < PG_PPT; ++r) arg[w * PG_PPT + r] = pgas_seg_arg(lw[w][r], kref);
         }
         pgas_exp_n(arg, ev, NW * PG_PPT);
 #pragma unroll
@@ -771,15 +772,9 @@ __device__ __forceinline__ void upper_core(SM& sm, const double* __restrict__ se
         g[c] = sm.red[c][0];
 #pragma unroll
         for (int v = 1; v < PG_UPPER_WAVES; ++v) g[c] = __builtin_fmax(g[c], sm.red[c][v]);
-        double arg[GPW], ev[GPW];
+        double ev[GPW];
 #pragma unroll
-        for (int e = 0; e < GPW; ++e) arg[e] = mv[c][e] - g[c];
-        if constexpr (GPW <= PGAS_NB) {
-            pgas_exp_n(arg, ev, GPW);
-        } else {
-#pragma unroll
-            for (int e = 0; e < GPW; ++e) ev[e] = pgas_exp(arg[e]);
-        }
+        for (int e = 0; e < GPW; ++e) ev[e] = pgas_seg_scale(mv[c][e], g[c]);  // exact power of two: no exp across segments
 #pragma unroll
         for (int e = 0; e < GPW; ++e) {
             const int gi = wave + PG_UPPER_WAVES * e;

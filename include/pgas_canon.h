@@ -26,6 +26,22 @@
 #define PGAS_MAX_D 3
 #define PGAS_MAX_J 64 /* distinct frequencies per basis dimension */
 
+/* ---- softmax reference of a segment.  The numerators of a segment are taken relative to a POWER OF TWO:
+ * kref = ceil(max_i lw_i * log2 e) (an integer-valued double, -inf for an empty segment), e_i = exp(lw_i - kref ln 2) in (0, 1]
+ * with the largest in (1/2, 1], so the 2^51 fixed point keeps at least 51 bits of it.  Across segments the common reference is
+ * K = max kref and the rescaling factor 2^(kref - K) is EXACT (one ldexp instead of one exp per segment and workgroup). */
+#define PGAS_SEG_LOG2E 0x1.71547652b82fep+0
+#define PGAS_SEG_LN2_HI 0x1.62e42fefa39efp-1
+#define PGAS_SEG_LN2_LO 0x1.abc9e3b39803fp-56
+PGAS_HD double pgas_seg_ref(double m) { return __builtin_ceil(m * PGAS_SEG_LOG2E); }
+PGAS_HD double pgas_seg_arg(double lw, double kref) {
+    return PGAS_FMA(-kref, PGAS_SEG_LN2_LO, PGAS_FMA(-kref, PGAS_SEG_LN2_HI, lw));
+}
+PGAS_HD double pgas_seg_scale(double kref, double K) {
+    const double d = kref - K; /* integer-valued and <= 0, -inf or NaN for empty segments */
+    return (d >= -1100.0) ? ldexp(1.0, (int)d) : 0.0;
+}
+
 /* Philox counter layout: (c0, c1, c2, c3) = (particle lo32, particle hi32, time step, stream | draw<<8),
  * key = (seed lo32, seed hi32). */
 #define PGAS_STREAM_INIT 1u     /* x_0 ~ N(m0, P0)          (src/PGAS.py:167-172) */

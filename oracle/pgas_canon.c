@@ -244,14 +244,15 @@ static void segment_scan(const double* lw, int n, double* mo, uint64_t* c, uint6
     double mx = -INFINITY;
     for (int i = 0; i < n; ++i)
         if (lw[i] > mx) mx = lw[i];
+    const double kref = pgas_seg_ref(mx); /* power-of-two reference, include/pgas_canon.h */
     uint64_t run = 0;
     for (int i = 0; i < n; ++i) {
-        double e = pgas_exp(lw[i] - mx);
+        double e = pgas_exp(pgas_seg_arg(lw[i], kref));
         uint64_t q = (e > 0.0) ? pgas_double_to_u64(__builtin_rint(e * PGAS_FIX_SCALE)) : 0;
         run += q;
         c[i] = run;
     }
-    *mo = mx;
+    *mo = kref;
     *so = run;
 }
 
@@ -310,8 +311,7 @@ static void upper_build(upper_t* U, int nseg, const double* segm, const uint64_t
     for (int b = 0; b < nseg; ++b)
         if (segm[b] > g) g = segm[b];
     for (int b = 0; b < nseg; ++b) {
-        double sc = pgas_exp(segm[b] - g);
-        if (!(sc >= 0.0)) sc = 0.0;
+        double sc = pgas_seg_scale(segm[b], g);
         U->scale[b] = sc;
         tot[b] = sc * (pgas_u64_to_double(segs[b]) * PGAS_FIX_INV);
     }
