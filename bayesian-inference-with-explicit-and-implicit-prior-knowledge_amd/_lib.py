@@ -38,6 +38,7 @@ EXPORTS = [
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
+    "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep",
     "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
 ]
 
@@ -96,6 +97,12 @@ def load():
     L.pgas_shard_set_peer.argtypes = [vp, i32, C.POINTER(vp)]
     L.pgas_shard_run.restype = C.c_int
     L.pgas_shard_run.argtypes = [vp, i32, i32, i32, u64, vp, vp, vp]
+    L.pgas_shard_unique_id.restype = C.c_int
+    L.pgas_shard_unique_id.argtypes = [C.c_char_p]
+    L.pgas_shard_comm_init.restype = C.c_int
+    L.pgas_shard_comm_init.argtypes = [vp, C.c_char_p]
+    L.pgas_shard_sweep.restype = C.c_int
+    L.pgas_shard_sweep.argtypes = [vp, u64, vp, vp, i32, vp]
     L.pgas_ipc_export.restype = C.c_int
     L.pgas_ipc_export.argtypes = [vp, i32, C.c_char_p]
     L.pgas_ipc_open.restype = C.c_int
@@ -341,6 +348,19 @@ class Engine:
                                     None if traj is None else traj.data_ptr(), self._stream()),
             "pgas_shard_run",
         )
+
+    def shard_unique_id(self):
+        buf = C.create_string_buffer(128)
+        rc = self.lib.pgas_shard_unique_id(buf)
+        if rc:
+            raise PgasError("pgas_shard_unique_id failed (librccl.so not loadable?)")
+        return bytes(buf.raw)
+
+    def shard_comm_init(self, id128):
+        self._chk(self.lib.pgas_shard_comm_init(self._h, id128), "pgas_shard_comm_init")
+
+    def shard_sweep(self, seed, ref, traj, propagate_chunk=0):
+        self._chk(self.lib.pgas_shard_sweep(self._h, int(seed), ref.data_ptr(), traj.data_ptr(), int(propagate_chunk), self._stream()), "pgas_shard_sweep")
 
     def ipc_export(self, which):
         buf = C.create_string_buffer(64)

@@ -2,6 +2,8 @@
 // pgas_kernels.hip.h.  Host side only: argument checking, device tables, launch sequencing.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 
 #include <cmath>
 #include <cstdio>
@@ -25,6 +27,37 @@
 namespace {
 
 thread_local std::string g_create_error;
+
+// RCCL is bound at run time (dlopen), so the library loads on machines without it and shares whichever RCCL the process
+// already has (PyTorch ships its own copy): only the particle-sharded sweep needs it.
+struct RcclApi {
+    ncclResult_t (*get_unique_id)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*init_rank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*all_gather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*group_start)() = nullptr;
+    ncclResult_t (*group_end)() = nullptr;
+    ncclResult_t (*destroy)(ncclComm_t) = nullptr;
+    const char* (*error_string)(ncclResult_t) = nullptr;
+    bool ok = false;
+};
+RcclApi& rccl() {
+    static RcclApi api = [] {
+        RcclApi a;
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.get_unique_id = (decltype(a.get_unique_id))dlsym(h, "ncclGetUniqueId");
+        a.init_rank = (decltype(a.init_rank))dlsym(h, "ncclCommInitRank");
+        a.all_gather = (decltype(a.all_gather))dlsym(h, "ncclAllGather");
+        a.group_start = (decltype(a.group_start))dlsym(h, "ncclGroupStart");
+        a.group_end = (decltype(a.group_end))dlsym(h, "ncclGroupEnd");
+        a.destroy = (decltype(a.destroy))dlsym(h, "ncclCommDestroy");
+        a.error_string = (decltype(a.error_string))dlsym(h, "ncclGetErrorString");
+        a.ok = a.get_unique_id && a.init_rank && a.all_gather && a.group_start && a.group_end && a.destroy;
+        return a;
+    }();
+    return api;
+}
 
 typedef void (*front_fn)(DevModel, TransParams, int, uint64_t, const double*, const double*, const double*, int, double*, ScanBufs);
 typedef void (*backc_fn)(DevModel, TransParams, int, uint64_t, double, const double*, const double*, ScanBufs, int32_t*, double*, double*);
@@ -76,6 +109,8 @@ struct pgas_ctx {
     backc_fn back_corrected = nullptr;
     int corrected = 0;          // PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE: propagate from the resampled ancestors (quirk Q1 removed)
     double* aux_buf = nullptr;  // (N, nx) transition means of the current step, corrected mode only
+    ncclComm_t comm = nullptr;  // RCCL communicator of the particle-sharded sweep (pgas_shard_comm_init)
+    int32_t* d_sync = nullptr;  // one word all-gathered at the end of a sharded sweep: orders peer reads before the next sweep's writes
     int32_t* d_fail = nullptr;  // failure counter of pgas_m_mniw_solve
     int mniw_valu = 0;          // PGAS_OPT_MNIW_VALU: 1 = column-by-column VALU factorisation instead of the MFMA-blocked one
     double* ws_partial = nullptr;  // per-chunk partial sums of pgas_m_weighted_stats
@@ -292,7 +327,8 @@ void pgas_destroy(pgas_ctx* c) {
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
     hipFree(c->segm_g[0]); hipFree(c->segm_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
-    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail); hipFree(c->ws_partial);
+    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail); hipFree(c->ws_partial); hipFree(c->d_sync);
+    if (c->comm && rccl().destroy) rccl().destroy(c->comm);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (hipEvent_t e : c->evp) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
@@ -814,6 +850,114 @@ int pgas_shard_run(pgas_ctx* c, int32_t phase, int32_t t, int32_t t_aux, uint64_
     default:
         FAIL(c, PGAS_E_ARG, "pgas_shard_run: unknown phase %d", phase);
     }
+}
+
+#define NCCLCHK(c, call)                                                                                                   \
+    do {                                                                                                                   \
+        ncclResult_t r_ = (call);                                                                                          \
+        if (r_ != ncclSuccess) FAIL(c, PGAS_E_HIP, "%s failed: %s", #call, rccl().error_string ? rccl().error_string(r_) : "RCCL error"); \
+    } while (0)
+
+int pgas_shard_unique_id(void* id128) {
+    if (!id128) return PGAS_E_ARG;
+    if (!rccl().ok) return PGAS_E_STATE;
+    return rccl().get_unique_id((ncclUniqueId*)id128) == ncclSuccess ? PGAS_OK : PGAS_E_HIP;
+}
+
+int pgas_shard_comm_init(pgas_ctx* c, const void* id128) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_comm_init: call pgas_shard_setup first");
+    if (!id128) FAIL(c, PGAS_E_ARG, "pgas_shard_comm_init: NULL id");
+    if (!rccl().ok) FAIL(c, PGAS_E_STATE, "pgas_shard_comm_init: librccl.so could not be loaded");
+    if (c->comm) return PGAS_OK;
+    HIPCHK(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof id);
+    NCCLCHK(c, rccl().init_rank(&c->comm, c->world, id, c->rank));
+    HIPCHK(c, hipMalloc(&c->d_sync, (size_t)(c->world + 1) * sizeof(int32_t)));
+    HIPCHK(c, hipMemset(c->d_sync, 0, (size_t)(c->world + 1) * sizeof(int32_t)));
+    return PGAS_OK;
+}
+
+// one collective: the (2, nsegp) partials of every rank -> (world, 2, nsegp), both arrays in one RCCL group
+static int shard_all_gather(pgas_ctx* c, int parity, hipStream_t st) {
+    const size_t cnt = 2 * (size_t)c->sb[parity].nsegp;
+    NCCLCHK(c, rccl().group_start());
+    NCCLCHK(c, rccl().all_gather(c->sb[parity].segm_w, c->segm_g[parity], cnt, ncclDouble, c->comm, st));
+    NCCLCHK(c, rccl().all_gather(c->sb[parity].segs_w, c->segs_g[parity], cnt, ncclUint64, c->comm, st));
+    NCCLCHK(c, rccl().group_end());
+    return PGAS_OK;
+}
+
+int pgas_shard_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_dev, int32_t propagate_chunk, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->sharded || !c->comm) FAIL(c, PGAS_E_STATE, "pgas_shard_sweep: call pgas_shard_setup and pgas_shard_comm_init first");
+    if (!ref_dev || !traj_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_sweep: NULL argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int T = c->md.T;
+    int rc = pgas_shard_run(c, PGAS_SHARD_INIT, 0, 0, seed, ref_dev, nullptr, stream);
+    if (rc) return rc;
+    // pipeline A (k_propagate, caller's stream) runs ahead chunk by chunk; pipeline B (resample, all-gather, cross-segment scan)
+    // follows on the internal stream, gated by one event per chunk -- as in pgas_sweep
+    const int chunk = propagate_chunk > 0 ? propagate_chunk : (c->overlap ? 16 : T);
+    const int nchunk = T > 1 ? (T - 1 + chunk - 1) / chunk : 0;
+    hipStream_t sb = st;
+    if (c->overlap && T > 1) {
+        if (!c->sB) {
+            int lo = 0, hi = 0;
+            HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, lo));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+        }
+        while ((int)c->ev_chunk.size() < nchunk) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->ev_chunk.push_back(e);
+        }
+        sb = c->sB;
+        HIPCHK(c, hipEventRecord(c->ev_start, st));
+        HIPCHK(c, hipStreamWaitEvent(sb, c->ev_start, 0));
+    }
+    for (int ci = 0; ci < nchunk; ++ci) {
+        const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+        rc = pgas_shard_run(c, PGAS_SHARD_PROPAGATE, t0, t1, seed, ref_dev, nullptr, st);
+        if (rc) return rc;
+        if (sb != st) {
+            HIPCHK(c, hipEventRecord(c->ev_chunk[ci], st));
+            HIPCHK(c, hipStreamWaitEvent(sb, c->ev_chunk[ci], 0));
+        }
+        const int tend = ci == nchunk - 1 ? T + 1 : t1;   // the last chunk also runs launch T
+        for (int t = t0; t < tend; ++t) {
+            rc = pgas_shard_run(c, PGAS_SHARD_RESAMPLE, t, 0, seed, nullptr, nullptr, sb);
+            if (rc) return rc;
+            if (t < T) {
+                rc = shard_all_gather(c, t & 1, sb);   // the one collective of the step (RCCL over xGMI), stream-ordered: no host round trip
+                if (rc) return rc;
+                rc = pgas_shard_run(c, PGAS_SHARD_UPPER, t, 0, seed, nullptr, nullptr, sb);
+                if (rc) return rc;
+            }
+        }
+    }
+    if (T == 1) {
+        rc = pgas_shard_run(c, PGAS_SHARD_RESAMPLE, 1, 0, seed, nullptr, nullptr, sb);
+        if (rc) return rc;
+    }
+    if (sb != st) {
+        HIPCHK(c, hipEventRecord(c->ev_done, sb));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_done, 0));
+    }
+    rc = pgas_shard_run(c, PGAS_SHARD_FINAL_SCAN, 0, 0, seed, nullptr, nullptr, stream);
+    if (rc) return rc;
+    rc = shard_all_gather(c, T & 1, st);
+    if (rc) return rc;
+    rc = pgas_shard_run(c, PGAS_SHARD_FINAL_UPPER, 0, 0, seed, nullptr, nullptr, stream);
+    if (rc) return rc;
+    rc = pgas_shard_run(c, PGAS_SHARD_BACKTRACE, 0, 0, seed, nullptr, traj_dev, stream);
+    if (rc) return rc;
+    // peers may still be chasing ancestors through this rank's traces: one more (tiny) collective closes the sweep on every rank
+    NCCLCHK(c, rccl().all_gather(c->d_sync + c->world, c->d_sync, 1, ncclInt32, c->comm, st));
+    return PGAS_OK;
 }
 
 /* xGMI / IPC plumbing for peers in OTHER processes: export a 64-byte handle of one of this context's buffers

@@ -71,6 +71,7 @@ class DistGroup:
         import torch.distributed as dist
 
         self.dist, self.group, self.shards = dist, group, [shard]
+        self.library_loop = False
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         handles = [shard.eng.ipc_export(k) for k in range(7)]
         everyone = [None] * world
@@ -80,6 +81,14 @@ class DistGroup:
                 shard.eng.shard_set_peer(peer, shard.ptrs[:7])
             else:
                 shard.eng.shard_set_peer(peer, [shard.eng.ipc_open(h) for h in hs])
+
+        if dist.get_backend(group) == "nccl":
+            # one process per GPU: the whole time loop runs inside the library, its per-step all-gather as an RCCL call on the
+            # sweep's stream (own communicator: torch.distributed only carries the 128-byte id)
+            ident = [shard.eng.shard_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0, group=group)
+            shard.eng.shard_comm_init(ident[0])
+            self.library_loop = True
 
     def all_gather(self, parity):
         s = self.shards[0]
@@ -110,6 +119,9 @@ def sharded_sweep(group, seed, ref, coeff_mat, error_cov, propagate_chunk=0):
         refs.append(r.to(device=s.eng.device, dtype=torch.float64).reshape(T, s.eng.nx).contiguous())
         trajs.append(torch.empty((T, s.eng.nx), dtype=torch.float64, device=s.eng.device))
     chunk = propagate_chunk if propagate_chunk > 0 else T
+    if getattr(group, "library_loop", False):
+        shards[0].eng.shard_sweep(seed, refs[0], trajs[0], propagate_chunk)   # pgas_shard_sweep: loop + RCCL inside the library
+        return trajs[0]
     for s, r in zip(shards, refs):
         s.eng.shard_run(PH_INIT, seed=seed, ref=r)
         for t0 in range(1, T, chunk):

@@ -167,6 +167,13 @@ int pgas_shard_buffers(pgas_ctx* ctx, void** out15, int64_t* sizes3);
 int pgas_shard_set_peer(pgas_ctx* ctx, int32_t peer, const void* const* bufs7);
 int pgas_shard_run(pgas_ctx* ctx, int32_t phase, int32_t t, int32_t t_aux, uint64_t seed, const double* ref_dev, double* traj_dev,
                    void* stream);
+/* The whole sharded sweep inside the library: pgas_shard_unique_id on one rank (128 bytes, to be broadcast by the host),
+ * pgas_shard_comm_init on every rank (ncclCommInitRank with the rank / world of pgas_shard_setup), then pgas_shard_sweep runs
+ * the phases above with the per-step all-gather issued as an RCCL call on the same stream -- no host round trip per step.
+ * RCCL is bound with dlopen at first use (PGAS_E_STATE if it cannot be loaded). */
+int pgas_shard_unique_id(void* id128);
+int pgas_shard_comm_init(pgas_ctx* ctx, const void* id128);
+int pgas_shard_sweep(pgas_ctx* ctx, uint64_t seed, const double* ref_dev, double* traj_dev, int32_t propagate_chunk, void* stream);
 int pgas_ipc_export(pgas_ctx* ctx, int32_t which, void* handle64);
 int pgas_ipc_open(pgas_ctx* ctx, const void* handle64, void** ptr);
 
