@@ -291,3 +291,43 @@ def trajectory_stats(alg, state_traj, int_var_traj):
         Ts = _calc_stats(np.asarray(int_var_traj[i], dtype=np.float64).reshape(T, -1), basis)
         out.append([np.sum(Ts[j], axis=0) for j in range(4)])
     return out
+
+
+class Algorithm2:
+    """src/Algorithm2.py:12-187: Particle Gibbs over Algorithm3.  `rands` yields one random-number provider per Gibbs iteration
+    (the reference splits its key once per iteration, :121)."""
+
+    def __init__(self, N_samples, N_iterations, observations, inputs, SSM, init_state_mean, init_state_cov, init_int_var_mean, init_int_var_cov,
+                 GP_prior, basis_fcn):
+        self.N_iterations = int(N_iterations)
+        self.N_steps = np.asarray(observations).shape[0]
+        self.cSMC = Algorithm3(N_samples, observations, inputs, SSM, init_state_mean, init_state_cov, init_int_var_mean, init_int_var_cov,
+                               GP_prior, basis_fcn)                                                   # :28-39
+
+    def __call__(self, rands, init_ref_state, init_ref_int_var):
+        c, K, T = self.cSMC, self.N_iterations, self.N_steps
+        nx = c.init_state_mean.shape[0]
+        state_trace = np.zeros((K, T, nx))                                                            # :46-54
+        state_trace[0] = np.asarray(init_ref_state, dtype=np.float64).reshape(T, nx)
+        int_var_trace = [np.zeros((K, T, m.shape[0])) for m in c.init_int_var_mean]                   # :56-67
+        for i in range(c.N_int):
+            int_var_trace[i][0] = np.asarray(init_ref_int_var[i], dtype=np.float64).reshape(T, -1)
+        sst = [[np.zeros((K, *g[0].shape)), np.zeros((K, *g[1].shape)), np.zeros((K, *g[2].shape)), np.zeros(K)] for g in c.GP_prior]   # :68-79
+        ref = trajectory_stats(c, state_trace[0], [v[0] for v in int_var_trace])                      # :81-93
+        for i in range(c.N_int):
+            for j in range(4):
+                sst[i][j][0] = ref[i][j]                                                              # :94-99
+        for k in range(1, K):                                                                         # :117-160
+            new_state, new_int_var, _ = c(next(rands), state_trace[k - 1], [v[k - 1] for v in int_var_trace],
+                                          [[sst[i][j][k - 1] for j in range(4)] for i in range(c.N_int)])   # :122-134
+            state_trace[k] = np.asarray(new_state).reshape(T, nx)                                     # :137
+            stats = trajectory_stats(c, state_trace[k], [np.asarray(v).reshape(T, -1) for v in new_int_var])
+            for i in range(c.N_int):
+                int_var_trace[i][k] = np.asarray(new_int_var[i]).reshape(T, -1)                       # :139
+                for j in range(4):
+                    sst[i][j][k] = stats[i][j]                                                        # :140-160
+        state_trace = np.swapaxes(state_trace, 0, 1)                                                  # :161
+        int_var_trace = [np.swapaxes(v, 0, 1) for v in int_var_trace]                                 # :162-165
+        obs = np.stack([np.asarray(c.SSM.output_mdl(state_trace[t], c.inputs[t], *[v[t] for v in int_var_trace])).reshape(K, -1) for t in range(T)])
+        ll = np.stack([c.SSM.log_likelihood(c.observations[t], state_trace[t], c.inputs[t], *[v[t] for v in int_var_trace]) for t in range(T)])
+        return state_trace, int_var_trace, np.ones((T, K)) / K, sst, obs, ll                          # :180-187
