@@ -22,7 +22,7 @@
 #define PG_W28 2
 #endif
 #ifndef PG_P3
-#define PG_P3 2   // particles per basis pass of the 3-D variants
+#define PG_P3 1   // particles per basis pass of the 3-D variants: 1 keeps k_propagate at 164 VGPRs (3 waves/SIMD; 2 -> 209 VGPRs, 2 waves)
 #endif
 namespace {
 
