@@ -559,8 +559,15 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
                 hipEvent_t e0 = timed ? c->ev[c->ev_used] : (hipEvent_t) nullptr, e1 = timed ? c->ev[c->ev_used + 1] : (hipEvent_t) nullptr;
                 if (timed) c->ev_used += 2;
                 if (fast) {
-                    hipExtLaunchKernelGGL(k_resample_fast, dim3(md.nseg + 1), blk, 0, sb_stream, e0, e1, 0, md, t, mode, ++c->launch_tag, u1p, u2p, la_t, h_t,
-                                          c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
+                    AncInputs ai;   // what the ancestor workgroup needs to rebuild one segment of the ancestor CDF of step s = t - 1
+                    ai.la_s = sp.laux;
+                    ai.h_s = c->h_buf + (size_t)(t > 1 ? t - 1 : 0) * np;
+                    ai.ln_p = t > 2 ? c->ln_buf + (size_t)(t - 2) * np : (const double*)nullptr;
+                    ai.la_p = t > 2 ? c->la_buf + (size_t)(t - 2) * np : (const double*)nullptr;
+                    ai.anc_p = t > 2 ? c->anc_trace + (size_t)(t - 3) * N : (const int32_t*)nullptr;
+                    ai.kref = sp.segm + sp.nsegp;
+                    hipExtLaunchKernelGGL(k_resample_fast, dim3(md.nseg + 1), blk, 0, sb_stream, e0, e1, 0, md, t, mode, ++c->launch_tag, u1p, u2p, ai, la_t,
+                                          h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
                     KCHK(c, "k_resample_fast");
                 } else {
                     hipExtLaunchKernelGGL(k_resample, grid, blk, 0, sb_stream, e0, e1, 0, md, t, mode, u1p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn,

@@ -488,7 +488,8 @@ struct ScanSmem {
     uint64_t wtot[2][PG_BLK / 64];
 };
 
-template <int NW>  // number of weight vectors scanned together (1 or 2)
+template <int NW, bool STORE_B = true>  // NW: weight vectors scanned together (1 or 2); STORE_B = false: the second one only leaves its
+                                         // segment partial (max, total) -- its per-particle cumsum is recomputed where it is needed
 __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW][PG_PPT], int seg, int nsegp,
                                              uint64_t* __restrict__ cA, uint64_t* __restrict__ cB, double* __restrict__ segm,
                                              uint64_t* __restrict__ segs) {
@@ -503,6 +504,7 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
         if (lane == 0) sm.red[w][wave] = m;
     }
     __syncthreads();
+    uint64_t qsum_b = 0;
     {
         double arg[NW * PG_PPT], ev[NW * PG_PPT];
 #pragma unroll
@@ -522,7 +524,8 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
             for (int r = 0; r < PG_PPT; ++r) {
                 const double e = ev[w * PG_PPT + r];
                 const uint64_t q = (e > 0.0) ? pgas_double_to_u64(__builtin_rint(e * PGAS_FIX_SCALE)) : 0ull;
-                sm.q[w][r * PG_BLK + tid] = q;
+                if (w == 0 || STORE_B) sm.q[w][r * PG_BLK + tid] = q;  // strided -> contiguous particle order for the prefix
+                else qsum_b += q;                                      // only the segment total is wanted: any order will do
             }
     }
     __syncthreads();
@@ -530,10 +533,14 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         uint64_t run = 0;
+        if (w == 0 || STORE_B) {
 #pragma unroll
-        for (int j = 0; j < PG_PPT; ++j) {
-            run += sm.q[w][PG_PPT * tid + j];
-            loc[w][j] = run;
+            for (int j = 0; j < PG_PPT; ++j) {
+                run += sm.q[w][PG_PPT * tid + j];
+                loc[w][j] = run;
+            }
+        } else {
+            run = qsum_b;
         }
         incl[w] = wave_incl_scan_u64(run);
         if (lane == 63) sm.wtot[w][wave] = incl[w];
@@ -548,10 +555,12 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
             if (v < wave) off += t;
             tot += t;
         }
-        const uint64_t base = off + incl[w] - loc[w][PG_PPT - 1];
-        ulonglong2* dst = reinterpret_cast<ulonglong2*>((w == 0 ? cA : cB) + (size_t)seg * PGAS_SEG + PG_PPT * tid);
-        dst[0] = make_ulonglong2(base + loc[w][0], base + loc[w][1]);
-        dst[1] = make_ulonglong2(base + loc[w][2], base + loc[w][3]);
+        if (w == 0 || STORE_B) {
+            const uint64_t base = off + incl[w] - loc[w][PG_PPT - 1];
+            ulonglong2* dst = reinterpret_cast<ulonglong2*>((w == 0 ? cA : cB) + (size_t)seg * PGAS_SEG + PG_PPT * tid);
+            dst[0] = make_ulonglong2(base + loc[w][0], base + loc[w][1]);
+            dst[1] = make_ulonglong2(base + loc[w][2], base + loc[w][3]);
+        }
         if (tid == 0) {
             segm[(size_t)w * nsegp + seg] = mx[w];
             segs[(size_t)w * nsegp + seg] = tot;
@@ -722,6 +731,7 @@ struct UpperSmemT {
     double red[2][PG_UPPER_WAVES];
     double par[3];                   // (excl, scale, carry) of one segment, broadcast for cdf_count_block
     int cnt[2];
+    unsigned long long wsum[PG_UPPER_WAVES];  // wave totals of cdf_count_block_recompute's integer scan
 };
 typedef UpperSmemT<PG_MAX_GROUPS> UpperSmem;
 
@@ -893,6 +903,90 @@ __device__ __forceinline__ int cdf_count_block(SM& sm, const double (&ex)[GPW], 
         double num = e0 + s0 * (pgas_u64_to_double(cseg[i]) * PGAS_FIX_INV);
         num = __builtin_fmax(num, cy);
         k += (num < tau) ? 1 : 0;
+    }
+    k = wave_sum_i(k);
+    if (lane == 0 && k) atomicAdd(&sm.cnt[1], k);
+    __syncthreads();
+    const int64_t r = base + sm.cnt[1];
+    return r > N - 1 ? N - 1 : (int)r;
+}
+
+// The ancestor CDF of a step (src/PGAS.py:117-124) is read in ONE segment only: the one the reference particle's uniform falls
+// into.  k_resample_fast therefore never stores its per-particle cumsum; the workgroup that draws the ancestor rebuilds that
+// segment from what the sweep already keeps in HBM -- lw2_i = (la_s[i] + logw_{s-1}[i]) + h_s[i] with
+// logw_{s-1}[i] = ln_{s-1}[i] - la_{s-1}[a_{s-1}[i]] (0 for s = 1), the same expressions, the segment's stored reference k,
+// the same fixed-point numerators and an exact integer cumsum -- and counts against it.  Bit-identical to the stored version.
+struct AncInputs {
+    const double* la_s;       // (np) log p(y_s | aux_s)
+    const double* h_s;        // (np) log N(ref_s; aux_s, S)
+    const double* ln_p;       // (np) log p(y_{s-1} | x_{s-1}), or nullptr for s = 1
+    const double* la_p;       // (np) log p(y_{s-1} | aux_{s-1})
+    const int32_t* anc_p;     // (N)  ancestors of step s-1
+    const double* kref;       // (nseg) segment references of the ancestor CDF of step s
+};
+template <int GPW, class SM>
+__device__ __forceinline__ int cdf_count_block_recompute(SM& sm, const double (&ex)[GPW], const double (&sc)[GPW], const double (&cmx)[GPW],
+                                                         int nseg, int N, double tau, const AncInputs& in) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < GPW; ++e) {
+        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
+        c += (b < nseg && cmx[e] < tau) ? 1 : 0;
+    }
+    c = wave_sum_i(c);
+    if (lane == 0 && c) atomicAdd(&sm.cnt[0], c);
+    if (tid == 0) sm.par[2] = 0.0;
+    __syncthreads();
+    const int bs = sm.cnt[0];
+    if (bs >= nseg) return N - 1;
+#pragma unroll
+    for (int e = 0; e < GPW; ++e) {
+        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
+        if (b == bs) {
+            sm.par[0] = ex[e];
+            sm.par[1] = sc[e];
+        }
+        if (b == bs - 1) sm.par[2] = cmx[e];
+    }
+    const int64_t base = (int64_t)bs * PGAS_SEG;
+    const int n = (N - base) < PGAS_SEG ? (int)(N - base) : PGAS_SEG;
+    const double kref = in.kref[bs];
+    double arg[PG_PPT], ev[PG_PPT];
+#pragma unroll
+    for (int j = 0; j < PG_PPT; ++j) {
+        const int i = PG_PPT * tid + j;
+        double lw2 = -__builtin_inf();
+        if (i < n) {
+            const int64_t gi = base + i;
+            double logw = 0.0;
+            if (in.ln_p) logw = in.ln_p[gi] - in.la_p[in.anc_p[gi]];
+            const double l1 = in.la_s[gi] + logw;
+            lw2 = l1 + in.h_s[gi];
+        }
+        arg[j] = pgas_seg_arg(lw2, kref);
+    }
+    pgas_exp_n(arg, ev, PG_PPT);
+    uint64_t loc[PG_PPT], run = 0;
+#pragma unroll
+    for (int j = 0; j < PG_PPT; ++j) {
+        run += (ev[j] > 0.0) ? pgas_double_to_u64(__builtin_rint(ev[j] * PGAS_FIX_SCALE)) : 0ull;
+        loc[j] = run;
+    }
+    const uint64_t incl = wave_incl_scan_u64(run);
+    if (lane == 63) sm.wsum[wave] = incl;
+    __syncthreads();
+    uint64_t off = incl - run;
+#pragma unroll
+    for (int v = 0; v < PG_UPPER_WAVES; ++v)
+        if (v < wave) off += sm.wsum[v];
+    const double e0 = sm.par[0], s0 = sm.par[1], cy = sm.par[2];
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < PG_PPT; ++j) {
+        double num = e0 + s0 * (pgas_u64_to_double(off + loc[j]) * PGAS_FIX_INV);
+        num = __builtin_fmax(num, cy);
+        k += (PG_PPT * tid + j < n && num < tau) ? 1 : 0;
     }
     k = wave_sum_i(k);
     if (lane == 0 && k) atomicAdd(&sm.cnt[1], k);
@@ -1332,7 +1426,7 @@ struct FastSmem {
 // The workgroup that owns the conditioned particle reads that word late (after its own search).  Workgroup 0 never
 // waits for anyone, so the hand-off cannot deadlock whatever the dispatch order; if the word has not arrived within the
 // spin budget the owner computes the ancestor itself (same code, same result).
-__global__ __launch_bounds__(PG_BLK, 5) void k_resample_fast(DevModel md, int t, int mode, unsigned tag, double u1_prev, double u2_prev,
+__global__ __launch_bounds__(PG_BLK, 5) void k_resample_fast(DevModel md, int t, int mode, unsigned tag, double u1_prev, double u2_prev, AncInputs anc_in,
                                                            const double* __restrict__ la_t, const double* __restrict__ h_t,
                                                            const double* __restrict__ ln_prev, ScanBufs sb_prev, ScanBufs sb_next,
                                                            int32_t* __restrict__ anc_out, double* __restrict__ logw_out) {
@@ -1346,7 +1440,7 @@ __global__ __launch_bounds__(PG_BLK, 5) void k_resample_fast(DevModel md, int t,
         upper_core<GPW, 1>(sm.up, sb_prev.segm + sb_prev.nsegp, sb_prev.segs + sb_prev.nsegp, 0, nseg, ex2, sc2, cm2, S2);
         int r = N - 1;
         if ((S2[0] > 0.0) && (S2[0] < __builtin_inf()))
-            r = cdf_count_block<GPW>(sm.up, ex2[0], sc2[0], cm2[0], nseg, N, u2_prev * S2[0], sb_prev.c2);
+            r = cdf_count_block_recompute<GPW>(sm.up, ex2[0], sc2[0], cm2[0], nseg, N, u2_prev * S2[0], anc_in);
         if (tid == 0)
             __hip_atomic_store(&sb_prev.hdr->ref_granule, ((unsigned long long)tag << 32) | (unsigned)r, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
@@ -1548,7 +1642,7 @@ __global__ __launch_bounds__(PG_BLK, 5) void k_resample_fast(DevModel md, int t,
                 upper_core<GPW, 1>(sm.up, sb_prev.segm + nsegp, sb_prev.segs + nsegp, 0, nseg, ex2, sc2, cm2, S2);
                 ref_idx = N - 1;
                 if ((S2[0] > 0.0) && (S2[0] < __builtin_inf()))
-                    ref_idx = cdf_count_block<GPW>(sm.up, ex2[0], sc2[0], cm2[0], nseg, N, u2_prev * S2[0], sb_prev.c2);
+                    ref_idx = cdf_count_block_recompute<GPW>(sm.up, ex2[0], sc2[0], cm2[0], nseg, N, u2_prev * S2[0], anc_in);
             }
 #pragma unroll
             for (int j = 0; j < PG_PPT; ++j)
@@ -1589,7 +1683,7 @@ __global__ __launch_bounds__(PG_BLK, 5) void k_resample_fast(DevModel md, int t,
             lw[1][r] = valid_p ? l1 + h_t[pi] : -__builtin_inf();
         }
         PG_STAMP(6);
-        segment_scan<2>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm_w, sb_next.segs_w);
+        segment_scan<2, false>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm_w, sb_next.segs_w);
     }
     PG_STAMP(7);
 }
