@@ -38,9 +38,11 @@ EXPORTS = [
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
-    "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep",
+    "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info",
     "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
 ]
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)   # pgas_allgather_fn (include/pgas_hip.h)
 
 _lib = None
 
@@ -103,6 +105,10 @@ def load():
     L.pgas_shard_comm_init.argtypes = [vp, C.c_char_p]
     L.pgas_shard_sweep.restype = C.c_int
     L.pgas_shard_sweep.argtypes = [vp, u64, vp, vp, i32, vp]
+    L.pgas_shard_set_collective.restype = C.c_int
+    L.pgas_shard_set_collective.argtypes = [vp, ALLGATHER_FN, vp]
+    L.pgas_get_launch_info.restype = C.c_int
+    L.pgas_get_launch_info.argtypes = [vp, C.POINTER(i32)]
     L.pgas_ipc_export.restype = C.c_int
     L.pgas_ipc_export.argtypes = [vp, i32, C.c_char_p]
     L.pgas_ipc_open.restype = C.c_int
@@ -332,8 +338,8 @@ class Engine:
         self.rank, self.world = rank, world
 
     def shard_buffers(self):
-        """(list of 15 device pointers, (nsegp, N_local, T)) -- see include/pgas_hip.h."""
-        out = (C.c_void_p * 15)()
+        """(list of 17 device pointers, (nsegp, N_local, T)) -- see include/pgas_hip.h."""
+        out = (C.c_void_p * 17)()
         sz = (C.c_int64 * 3)()
         self._chk(self.lib.pgas_shard_buffers(self._h, out, sz), "pgas_shard_buffers")
         return [int(p or 0) for p in out], tuple(int(v) for v in sz)
@@ -359,8 +365,37 @@ class Engine:
     def shard_comm_init(self, id128):
         self._chk(self.lib.pgas_shard_comm_init(self._h, id128), "pgas_shard_comm_init")
 
+    def shard_set_collective(self, fn):
+        """Install a host all-gather `fn(parity, stream_ptr) -> int` in place of RCCL for pgas_shard_sweep (tests); None removes it."""
+        if fn is None:
+            self._ag_cb = None
+            self._chk(self.lib.pgas_shard_set_collective(self._h, C.cast(None, ALLGATHER_FN), None), "pgas_shard_set_collective")
+            return
+
+        def tramp(user, parity, stream):
+            try:
+                return int(fn(int(parity), stream) or 0)
+            except Exception as exc:  # an exception must not unwind through the C frames
+                import traceback
+
+                self._ag_error = "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))
+                return -1
+
+        self._ag_cb = ALLGATHER_FN(tramp)   # keep the trampoline alive as long as the library may call it
+        self._chk(self.lib.pgas_shard_set_collective(self._h, self._ag_cb, None), "pgas_shard_set_collective")
+
+    def launch_info(self):
+        """dict(chunk, local_groups, JP, P) of the last sweep (pgas_get_launch_info)."""
+        v = (C.c_int32 * 4)()
+        self._chk(self.lib.pgas_get_launch_info(self._h, v), "pgas_get_launch_info")
+        return dict(chunk=int(v[0]), local_groups=bool(v[1]), JP=int(v[2]), P=int(v[3]))
+
     def shard_sweep(self, seed, ref, traj, propagate_chunk=0):
-        self._chk(self.lib.pgas_shard_sweep(self._h, int(seed), ref.data_ptr(), traj.data_ptr(), int(propagate_chunk), self._stream()), "pgas_shard_sweep")
+        self._ag_error = None
+        rc = self.lib.pgas_shard_sweep(self._h, int(seed), ref.data_ptr(), traj.data_ptr(), int(propagate_chunk), self._stream())
+        if rc != 0 and getattr(self, "_ag_error", None):
+            raise PgasError(f"pgas_shard_sweep: the all-gather callback raised:\n{self._ag_error}")
+        self._chk(rc, "pgas_shard_sweep")
 
     def ipc_export(self, which):
         buf = C.create_string_buffer(64)

@@ -14,6 +14,7 @@
 
 #include "../../include/pgas_hip.h"
 #include "pgas_kernels.hip.h"
+#include "pgas_resample.hip.h"
 #include "pgas_suffstats.hip.h"
 #include "pgas_marginal.hip.h"
 #include "../../include/pgas_marginal.h"
@@ -59,11 +60,27 @@ RcclApi& rccl() {
     return api;
 }
 
+// Every entry point runs on its context's device and puts the caller's current device back on return (all paths, errors included):
+// a process that drives several contexts, or keeps torch tensors on another device, must not see its current device change.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+        else if (prev < 0) (void)hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 typedef void (*front_fn)(DevModel, TransParams, int, uint64_t, const double*, const double*, const double*, int, double*, ScanBufs);
-typedef void (*backc_fn)(DevModel, TransParams, int, uint64_t, double, const double*, const double*, ScanBufs, int32_t*, double*, double*);
+typedef void (*backc_fn)(DevModel, TransParams, int, uint64_t, double, const double*, const double*, ScanBufs, Peers, int32_t*, double*, double*);
 typedef void (*prop_fn)(DevModel, TransParams, uint64_t, int, int, double*, const double*, double*, double*, double*);
 typedef void (*aux_fn)(DevModel, TransParams, int, const double*, double*);
-typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, int32_t*, double*);
+typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, Peers, int32_t*, double*);
 typedef void (*init_fn)(DevModel, uint64_t, const double*, const double*, double*);
 typedef void (*basis_fn)(DevModel, const int32_t*, const double*, int64_t, int, double*);
 
@@ -71,11 +88,12 @@ struct Variant {
     front_fn front;
     prop_fn prop;
     aux_fn aux;
+    int P, W;   // particles per basis pass, waves per SIMD the k_propagate instantiation is built for
 };
 
 template <int NX, int D, int JIN, int P, int W>
 Variant make_variant() {
-    return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W>, k_aux<NX, D, JIN, P>};
+    return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W>, k_aux<NX, D, JIN, P>, P, W};
 }
 
 // (nx, D, padded innermost extent) -> kernel instantiation <NX, D, JIN, P particles per basis pass, W waves/SIMD>
@@ -144,13 +162,17 @@ struct pgas_ctx {
     const uint64_t* peer_c2[2][PG_MAX_RANKS] = {};
     bool sharded = false;
     int rank = 0, world = 1;
-    double* segm_g[2] = {nullptr, nullptr};   // gathered partials (sharded mode): (world, 2, nsegp) per scan buffer
+    double* segk_g[2] = {nullptr, nullptr};   // gathered partials (sharded mode): (world, 2, nsegp) per scan buffer
     uint64_t* segs_g[2] = {nullptr, nullptr};
-    unsigned launch_tag = 0;    // unique id per k_resample_fast launch (hand-off word tag)
-    int force_slow = 0;         // 1: never use k_resample_fast (test hook for the k_resample + k_upper path)
+    pgas_allgather_fn ag_cb = nullptr;        // host-staged all-gather installed by pgas_shard_set_collective (tests); NULL = RCCL
+    void* ag_user = nullptr;
+    int last_chunk = 0;         // time steps per k_propagate launch of the last sweep
+    int var_P = 0;              // particles per basis pass of the k_propagate variant
+    unsigned launch_tag = 0;    // unique id per k_step launch (hand-off word tag)
+    int force_slow = 0;         // 1: never let k_step scan the groups itself (test hook for the k_groups path taken when N > 2^20 per device)
     int overlap = 1;            // 1: run the weight recursion on an internal stream concurrently with k_propagate
     int prop_lds = 0;   // dynamic LDS reserved per k_propagate workgroup when overlapping: caps it at two workgroups per CU so
-                                // that two k_resample_fast workgroups (25.5 KB LDS, 96 VGPRs) always fit beside them
+                                // that two k_step workgroups always fit beside them
     hipStream_t sB = nullptr;   // internal stream of the weight recursion
     std::vector<hipEvent_t> ev_chunk;  // "k_propagate chunk c done" events
     hipEvent_t ev_start = nullptr, ev_done = nullptr;
@@ -159,7 +181,7 @@ struct pgas_ctx {
     // optional per-launch timing of the dominant kernel (pgas_set_profiling)
     int profiling = 0;
     int prof_stride = 16;       // every prof_stride-th launch carries start/stop events (hipExtLaunchKernelGGL: the dispatch's own timestamps)
-    std::vector<hipEvent_t> ev;      // pairs (start, stop) around each k_resample launch of the last sweep
+    std::vector<hipEvent_t> ev;      // pairs (start, stop) around each k_step launch of the last sweep
     std::vector<hipEvent_t> evp;     // pairs (start, stop) around each k_propagate launch of the last sweep
     int evp_used = 0;
     int ev_used = 0;
@@ -194,23 +216,25 @@ static int alloc_scanbufs(pgas_ctx* c, ScanBufs* sb) {
     HIPCHK(c, hipMalloc(&sb->laux, np * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->c1, np * sizeof(uint64_t)));
     HIPCHK(c, hipMalloc(&sb->c2, np * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc(&sb->segm, 2 * nsegp * sizeof(double)));
-    HIPCHK(c, hipMalloc(&sb->segs, 2 * nsegp * sizeof(uint64_t)));
-    HIPCHK(c, hipMalloc(&sb->excl, 2 * nsegp * sizeof(double)));
-    HIPCHK(c, hipMalloc(&sb->scale, 2 * nsegp * sizeof(double)));
-    HIPCHK(c, hipMalloc(&sb->cm, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->segk_w, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->segs_w, 2 * nsegp * sizeof(uint64_t)));
+    HIPCHK(c, hipMalloc(&sb->tab_e, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->tab_sc, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->tab_m, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->grp_K, 2 * PG_MAX_GRP * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->grp_T, 2 * PG_MAX_GRP * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->hdr, sizeof(UpperHdr)));
     HIPCHK(c, hipMemset(sb->hdr, 0, sizeof(UpperHdr)));
-    sb->segm_w = sb->segm;
-    sb->segs_w = sb->segs;
+    sb->segk = sb->segk_w;
+    sb->segs = sb->segs_w;
     sb->nseg_l = 0x40000000;
     sb->rank_stride = 0;
     sb->nsegp_g = nsegp;
     return PGAS_OK;
 }
 static void free_scanbufs(ScanBufs* sb) {
-    hipFree(sb->laux); hipFree(sb->c1); hipFree(sb->c2); hipFree(sb->segm_w); hipFree(sb->segs_w);  // segm/segs alias these or the gathered arrays
-    hipFree(sb->excl); hipFree(sb->scale); hipFree(sb->cm); hipFree(sb->hdr);
+    hipFree(sb->laux); hipFree(sb->c1); hipFree(sb->c2); hipFree(sb->segk_w); hipFree(sb->segs_w);  // segk/segs alias these or the gathered arrays
+    hipFree(sb->tab_e); hipFree(sb->tab_sc); hipFree(sb->tab_m); hipFree(sb->grp_K); hipFree(sb->grp_T); hipFree(sb->hdr);
     *sb = ScanBufs{};
 }
 
@@ -236,7 +260,7 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
     md.N = d->N; md.T = d->T; md.nx = d->nx; md.ny = d->ny; md.nu = d->nu; md.D = d->D; md.M = d->M;
     md.nseg = (int)nseg64;
     md.p0 = 0; md.Ng = d->N; md.nseg_g = md.nseg;
-    c->peers.world = 1; c->peers.nseg_l = md.nseg; c->peers.Nl = d->N;
+    c->peers = Peers{}; c->peers.world = 1; c->peers.nseg_l = md.nseg; c->peers.Nl = d->N;
     md.nrm = d->nrm; md.cR = d->cR;
     for (int k = 0; k < d->D; ++k) {
         if (d->sel[k] < 0 || d->sel[k] >= d->nx + d->nu) FAIL(c, PGAS_E_ARG, "pgas_create: sel[%d] = %d out of range", k, d->sel[k]);
@@ -263,13 +287,13 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
     for (int j = 0; j < d->ny * d->ny; ++j) md.LRinv[j] = d->LRinv[j];
     if (!pick_variant(d->nx, d->D, md.J[d->D - 1], &c->var, &md.JP))
         FAIL(c, PGAS_E_ARG, "pgas_create: innermost basis dimension has %d frequencies (compiled up to 16)", md.J[d->D - 1]);
+    c->var_P = c->var.P;
     c->back = d->nx == 1 ? k_back<1> : k_back<2>;
     c->back_corrected = d->nx == 1 ? k_back_corrected<1> : k_back_corrected<2>;
     c->init = d->nx == 1 ? k_init<1> : k_init<2>;
     c->basis = d->nx == 1 ? k_basis_eval<1> : k_basis_eval<2>;
     c->keep_logw = d->keep_logw_trace;
 
-    HIPCHK(c, hipSetDevice(d->device));
     c->device = d->device;
     // grid positions of the basis functions, innermost dimension padded to JP
     std::vector<int32_t> pos(d->M);
@@ -310,7 +334,11 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
 int pgas_create(const pgas_model_desc* desc, pgas_ctx** out) {
     if (!desc || !out) { g_create_error = "pgas_create: NULL argument"; return PGAS_E_ARG; }
     pgas_ctx* c = new pgas_ctx();
-    int rc = create_impl(desc, c);
+    c->device = desc->device;
+    DeviceGuard guard(desc->device);
+    int dev_now = -1;
+    int rc = (hipGetDevice(&dev_now) == hipSuccess && dev_now == desc->device) ? create_impl(desc, c) : PGAS_E_HIP;
+    if (rc == PGAS_E_HIP && c->err.empty()) c->err = "pgas_create: cannot select the HIP device";
     if (rc != PGAS_OK) {
         g_create_error = c->err;
         pgas_destroy(c);
@@ -323,10 +351,10 @@ int pgas_create(const pgas_model_desc* desc, pgas_ctx** out) {
 
 void pgas_destroy(pgas_ctx* c) {
     if (!c) return;
-    hipSetDevice(c->device);
+    DeviceGuard guard(c->device);
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
-    hipFree(c->segm_g[0]); hipFree(c->segm_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
+    hipFree(c->segk_g[0]); hipFree(c->segk_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
     hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail); hipFree(c->ws_partial); hipFree(c->d_sync);
     if (c->comm && rccl().destroy) rccl().destroy(c->comm);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
@@ -343,7 +371,7 @@ void pgas_destroy(pgas_ctx* c) {
 int pgas_set_params(pgas_ctx* c, const double* A_dev, const double* LS_host, const double* LSinv_host, double cS, void* stream) {
     if (!c) return PGAS_E_ARG;
     if (!A_dev || !LS_host || !LSinv_host) FAIL(c, PGAS_E_ARG, "pgas_set_params: NULL argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
     const int nx = c->md.nx;
     for (int i = 0; i < 4; ++i) { c->tp.LS[i] = 0.0; c->tp.LSinv[i] = 0.0; }
@@ -366,7 +394,7 @@ int pgas_basis_eval(pgas_ctx* c, const double* x_dev, int64_t np, int32_t t, dou
     if (!c) return PGAS_E_ARG;
     if (!x_dev || !phi_dev || np < 0 || t < 0 || t >= c->md.T) FAIL(c, PGAS_E_ARG, "pgas_basis_eval: bad argument");
     if (np == 0) return PGAS_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipLaunchKernelGGL(c->basis, dim3((unsigned)((np + PG_BLK - 1) / PG_BLK)), dim3(PG_BLK), 0, (hipStream_t)stream, c->md, c->d_idx, x_dev, np, t, phi_dev);
     KCHK(c, "k_basis_eval");
     return PGAS_OK;
@@ -376,7 +404,7 @@ int pgas_aux_states(pgas_ctx* c, const double* x_dev, int32_t t, double* aux_dev
     if (!c) return PGAS_E_ARG;
     if (!x_dev || !aux_dev || t < 0 || t >= c->md.T) FAIL(c, PGAS_E_ARG, "pgas_aux_states: bad argument");
     if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_aux_states: call pgas_set_params first");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipLaunchKernelGGL(c->var.aux, dim3(c->md.nseg), dim3(PG_BLK), 0, (hipStream_t)stream, c->md, c->tp, t, x_dev, aux_dev);
     KCHK(c, "k_aux");
     return PGAS_OK;
@@ -385,7 +413,7 @@ int pgas_aux_states(pgas_ctx* c, const double* x_dev, int32_t t, double* aux_dev
 int pgas_init_state(pgas_ctx* c, uint64_t seed, const double* ref0_host, double* x0_dev, void* stream) {
     if (!c) return PGAS_E_ARG;
     if (!ref0_host || !x0_dev) FAIL(c, PGAS_E_ARG, "pgas_init_state: NULL argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(c, hipMemcpyAsync(c->d_ref, ref0_host, c->md.nx * sizeof(double), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(c->init, dim3((c->md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, c->md, seed, c->d_m0L0, c->d_ref, x0_dev);
@@ -393,11 +421,70 @@ int pgas_init_state(pgas_ctx* c, uint64_t seed, const double* ref0_host, double*
     return PGAS_OK;
 }
 
-static int launch_upper(pgas_ctx* c, const ScanBufs& sb, int nblocks, int search_block, double u, int final_mode, hipStream_t st) {
-    const int groups = (c->md.nseg_g + 63) / 64;
-    auto kern = groups <= 4 * PG_UPPER_WAVES ? k_upper<4> : groups <= 8 * PG_UPPER_WAVES ? k_upper<8> : k_upper<PG_MAX_GROUPS / PG_UPPER_WAVES>;
-    hipLaunchKernelGGL(kern, dim3(nblocks), dim3(PG_UPPER_THREADS), 0, st, c->md.Ng, c->md.nseg_g, sb, c->peers, search_block, u, final_mode);
-    KCHK(c, "k_upper");
+// ---- launch helpers of the weight recursion (pgas_resample.hip.h) ---------------------------------------------------
+static Peers peers_for(const pgas_ctx* c, int parity) {
+    Peers p = c->peers;
+    for (int r = 0; r < p.world; ++r) {
+        p.c1[r] = c->peer_c1[parity][r];
+        p.c2[r] = c->peer_c2[parity][r];
+    }
+    return p;
+}
+
+// this context's own buffers as "rank" c->rank of the peer table (single device: rank 0)
+static void install_own_peers(pgas_ctx* c) {
+    const int r = c->rank;
+    c->peers.la[r] = c->la_buf; c->peers.h[r] = c->h_buf; c->peers.ln[r] = c->ln_buf;
+    c->peers.x[r] = c->x_trace; c->peers.anc[r] = c->anc_trace;
+    for (int i = 0; i < 2; ++i) {
+        c->peer_c1[i][r] = c->sb[i].c1;
+        c->peer_c2[i][r] = c->sb[i].c2;
+    }
+}
+
+// group records of `ncdf` CDFs from the (gathered) segment partials of sb
+static int launch_groups(pgas_ctx* c, const ScanBufs& sb, int ncdf, hipStream_t st) {
+    const int n1 = (c->md.nseg_g + PG_GRP - 1) / PG_GRP;
+    hipLaunchKernelGGL(k_groups, dim3((n1 * ncdf + 3) / 4), dim3(256), 0, st, c->md.nseg_g, ncdf, sb);
+    KCHK(c, "k_groups");
+    return PGAS_OK;
+}
+
+// what = 0: ancestor of the conditioned particle (step API), 1: final index
+static int launch_count(pgas_ctx* c, const ScanBufs& sb, int parity, int what, double u, hipStream_t st) {
+    hipLaunchKernelGGL(k_count, dim3(1), dim3(PG_BLK), 0, st, c->md.Ng, c->md.nseg_g, sb, peers_for(c, parity), what, u);
+    KCHK(c, "k_count");
+    return PGAS_OK;
+}
+
+static bool sweep_is_local(const pgas_ctx* c) { return c->world == 1 && !c->sharded && c->md.nseg_g <= PG_LOCAL_NSEG && !c->force_slow; }
+
+// launch t in [1, T] of the sweep: resamples step t-1 (t > 1), scans step t (t < T)
+static int launch_step(pgas_ctx* c, int t, uint64_t seed, bool local, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+    const DevModel& md = c->md;
+    const int N = md.N, T = md.T;
+    const size_t np = (size_t)md.nseg * PGAS_SEG;
+    StepArgs ar;
+    ar.t = t;
+    ar.mode = (t < T ? PG_RS_SCAN : 0) | (t > 1 ? PG_RS_SEARCH : 0);
+    ar.tag = ++c->launch_tag;
+    ar.u1_prev = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)) : 0.0;
+    ar.u2_prev = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)(t - 1)) : 0.0;
+    ar.la_t = t < T ? c->la_buf + (size_t)t * np : (const double*)nullptr;
+    ar.h_t = t < T ? c->h_buf + (size_t)t * np : (const double*)nullptr;
+    ar.ln_prev = c->ln_buf + (size_t)(t - 1) * np;
+    ar.row_prev = (int64_t)((size_t)(t - 1) * np);
+    ar.anc_in.row_s = (int64_t)((size_t)(t - 1) * np);
+    ar.anc_in.row_p = t > 2 ? (int64_t)((size_t)(t - 2) * np) : -1;
+    ar.anc_in.anc_row_p = t > 2 ? (int64_t)((size_t)(t - 3) * N) : 0;
+    ar.anc_out = t > 1 ? c->anc_trace + (size_t)(t - 2) * N : (int32_t*)nullptr;
+    ar.logw_out = t == T ? c->logw_last : ((c->logw_trace && t > 1) ? c->logw_trace + (size_t)(t - 1) * N : (double*)nullptr);
+    const ScanBufs& sp = c->sb[(t - 1) & 1];
+    const ScanBufs& sn = c->sb[t & 1];
+    const Peers pr = peers_for(c, (t - 1) & 1);
+    if (local) hipExtLaunchKernelGGL(k_step<true>, dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    else hipExtLaunchKernelGGL(k_step<false>, dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    KCHK(c, "k_step");
     return PGAS_OK;
 }
 
@@ -407,22 +494,27 @@ int pgas_step(pgas_ctx* c, int32_t t, uint64_t seed, const double* logw_dev, con
     if (!x_dev || !ref_t_host || !logw_new_dev || !x_new_dev || !anc_dev) FAIL(c, PGAS_E_ARG, "pgas_step: NULL argument");
     if (t < 0 || t >= c->md.T) FAIL(c, PGAS_E_ARG, "pgas_step: t = %d outside [0, %d)", t, c->md.T);
     if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_step: call pgas_set_params first");
-    HIPCHK(c, hipSetDevice(c->device));
+    if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_step: not available on a shard context");
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
     const DevModel& md = c->md;
+    install_own_peers(c);
     HIPCHK(c, hipMemcpyAsync(c->d_ref, ref_t_host, md.nx * sizeof(double), hipMemcpyHostToDevice, st));
     if (c->corrected && !c->aux_buf) HIPCHK(c, hipMalloc(&c->aux_buf, (size_t)md.N * md.nx * sizeof(double)));
     hipLaunchKernelGGL(c->var.front, dim3(md.nseg), dim3(PG_BLK), 0, st, md, c->tp, t, seed, x_dev, logw_dev, c->d_ref, c->corrected,
                        c->corrected ? c->aux_buf : x_new_dev, c->sb[0]);
     KCHK(c, "k_front");
-    int rc = launch_upper(c, c->sb[0], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
+    int rc = launch_groups(c, c->sb[0], 2, st);
     if (rc) return rc;
+    rc = launch_count(c, c->sb[0], 0, 0, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), st);
+    if (rc) return rc;
+    const Peers pr = peers_for(c, 0);
     if (c->corrected) {
         hipLaunchKernelGGL(c->back_corrected, dim3(md.nseg), dim3(PG_BLK), 0, st, md, c->tp, t, seed,
-                           pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), c->aux_buf, c->d_ref, c->sb[0], anc_dev, x_new_dev, logw_new_dev);
+                           pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), c->aux_buf, c->d_ref, c->sb[0], pr, anc_dev, x_new_dev, logw_new_dev);
     } else {
         hipLaunchKernelGGL(c->back, dim3(md.nseg), dim3(PG_BLK), 0, st, md, t,
-                           pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), x_new_dev, c->sb[0], anc_dev, logw_new_dev);
+                           pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), x_new_dev, c->sb[0], pr, anc_dev, logw_new_dev);
     }
     KCHK(c, "k_back");
     return PGAS_OK;
@@ -443,6 +535,124 @@ static int ensure_traces(pgas_ctx* c) {
         HIPCHK(c, hipMalloc(&c->logw_trace, (size_t)md.T * md.N * sizeof(double)));
         HIPCHK(c, hipMemset(c->logw_trace, 0, (size_t)md.T * md.N * sizeof(double)));
     }
+    install_own_peers(c);
+    return PGAS_OK;
+}
+
+// k_propagate for time steps [t0, t1), optionally carrying dispatch-attached events
+static int launch_propagate(pgas_ctx* c, uint64_t seed, int t0, int t1, const double* ref_dev, hipStream_t st, bool timed) {
+    const dim3 grid(c->md.nseg), blk(PG_BLK);
+    const size_t lds = c->overlap ? c->prop_lds : 0;
+    if (timed) {
+        while ((int)c->evp.size() < c->evp_used + 2) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreate(&e));
+            c->evp.push_back(e);
+        }
+        // start/stop events bound to the dispatch itself: they carry the kernel's own begin/end timestamps
+        hipExtLaunchKernelGGL(c->var.prop, grid, blk, lds, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, c->md, c->tp, seed, t0, t1, c->x_trace,
+                              ref_dev, c->la_buf, c->h_buf, c->ln_buf);
+        c->evp_used += 2;
+    } else {
+        hipLaunchKernelGGL(c->var.prop, grid, blk, lds, st, c->md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
+    }
+    KCHK(c, "k_propagate");
+    return PGAS_OK;
+}
+
+static int ensure_side_stream(pgas_ctx* c, int nchunk) {
+    if (!c->sB) {
+        int lo = 0, hi = 0;
+        HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+        // measured (tools/overlap_exp.sh): the chain stream at LOW priority and one-step k_propagate launches overlap best
+        HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, lo));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    }
+    while ((int)c->ev_chunk.size() < nchunk) {
+        hipEvent_t e;
+        HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_chunk.push_back(e);
+    }
+    return PGAS_OK;
+}
+
+// One collective of the sharded sweep: the (2, nsegp) segment partials of every rank -> (world, 2, nsegp).  RCCL by default
+// (both arrays in one group, on the sweep's stream); a host callback when the caller installed one (tests on one device).
+static int shard_all_gather(pgas_ctx* c, int parity, hipStream_t st);
+
+// The time loop shared by pgas_sweep and pgas_shard_sweep: pipeline A (k_propagate, caller's stream) runs ahead chunk by chunk,
+// pipeline B (k_step [+ all-gather + k_groups]) follows on the internal stream, gated by one event per chunk.
+static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int chunk, hipStream_t st) {
+    const DevModel& md = c->md;
+    const int T = md.T;
+    const bool local = sweep_is_local(c);
+    const int nchunk = (T - 1 + chunk - 1) / chunk;
+    hipStream_t sB = st;
+    if (c->overlap) {
+        int rc = ensure_side_stream(c, nchunk);
+        if (rc) return rc;
+        sB = c->sB;
+        HIPCHK(c, hipEventRecord(c->ev_start, st));
+        HIPCHK(c, hipStreamWaitEvent(sB, c->ev_start, 0));
+    }
+    if (c->profiling && (int)c->ev.size() < 2 * T) {
+        const size_t old = c->ev.size();
+        c->ev.resize(2 * (size_t)T);
+        for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
+    }
+    // launches are issued chunk by chunk, pipeline A first, so both device queues stay fed
+    for (int ci = 0; ci < nchunk; ++ci) {
+        const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+        int rc = launch_propagate(c, seed, t0, t1, ref_dev, st, c->profiling && (ci % c->prof_stride) == 0);
+        if (rc) return rc;
+        if (sB != st) {
+            HIPCHK(c, hipEventRecord(c->ev_chunk[ci], st));
+            HIPCHK(c, hipStreamWaitEvent(sB, c->ev_chunk[ci], 0));
+        }
+        // launch t resamples step t-1 (t > 1) and scans step t (t < T); the last chunk also runs launch T
+        const int tend = ci == nchunk - 1 ? T + 1 : t1;
+        for (int t = t0; t < tend; ++t) {
+            const bool timed = c->profiling && t < T && (t % c->prof_stride) == 0;
+            hipEvent_t e0 = timed ? c->ev[c->ev_used] : (hipEvent_t) nullptr, e1 = timed ? c->ev[c->ev_used + 1] : (hipEvent_t) nullptr;
+            if (timed) c->ev_used += 2;
+            rc = launch_step(c, t, seed, local, sB, e0, e1);
+            if (rc) return rc;
+            if (!local && t < T) {
+                if (c->sharded) {
+                    rc = shard_all_gather(c, t & 1, sB);   // the one collective of the step, stream-ordered: no host round trip
+                    if (rc) return rc;
+                }
+                rc = launch_groups(c, c->sb[t & 1], 2, sB);
+                if (rc) return rc;
+            }
+        }
+    }
+    if (sB != st) {
+        HIPCHK(c, hipEventRecord(c->ev_done, sB));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_done, 0));
+    }
+    return PGAS_OK;
+}
+
+// final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
+static int run_final(pgas_ctx* c, uint64_t seed, double* traj_dev, hipStream_t st) {
+    const DevModel& md = c->md;
+    const int T = md.T;
+    const ScanBufs& sf = c->sb[T & 1];
+    hipLaunchKernelGGL(k_segscan, dim3(md.nseg), dim3(PG_BLK), 0, st, md.N, c->logw_last, sf);
+    KCHK(c, "k_segscan");
+    int rc;
+    if (c->sharded) {
+        rc = shard_all_gather(c, T & 1, st);
+        if (rc) return rc;
+    }
+    rc = launch_groups(c, sf, 1, st);
+    if (rc) return rc;
+    rc = launch_count(c, sf, T & 1, 1, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, st, md.N, T, md.nx, c->x_trace, c->anc_trace, c->peers, sf.hdr, traj_dev);
+    KCHK(c, "k_backtrace");
     return PGAS_OK;
 }
 
@@ -450,8 +660,8 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     if (!c) return PGAS_E_ARG;
     if (!ref_dev || !traj_dev) FAIL(c, PGAS_E_ARG, "pgas_sweep: NULL argument");
     if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_sweep: call pgas_set_params first");
-    if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_sweep: this context is a shard; drive it with pgas_shard_run");
-    HIPCHK(c, hipSetDevice(c->device));
+    if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_sweep: this context is a shard; drive it with pgas_shard_sweep");
+    DeviceGuard guard(c->device);
     int rc = ensure_traces(c);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
@@ -467,135 +677,37 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     if (T == 1) {
         HIPCHK(c, hipMemsetAsync(c->logw_last, 0, N * sizeof(double), st));
     } else if (c->corrected) {
-        // corrected mode: x_t depends on the ancestors a_t, so the step is a serial chain of three launches on one stream
-        // (transition means + scans, cross-segment scan + reference ancestor, search + propagate + weights)
+        // corrected mode: x_t depends on the ancestors a_t, so the step is a serial chain on one stream
+        // (transition means + scans, group scans, reference ancestor, search + propagate + weights)
         if (!c->aux_buf) HIPCHK(c, hipMalloc(&c->aux_buf, row * sizeof(double)));
+        const Peers pr = peers_for(c, 0);
         for (int t = 1; t < T; ++t) {
             const double* lw_prev = t == 1 ? (const double*)nullptr : (c->logw_trace ? c->logw_trace + (size_t)(t - 1) * N : c->logw_last);
             double* lw_out = c->logw_trace ? c->logw_trace + (size_t)t * N : c->logw_last;
             hipLaunchKernelGGL(c->var.front, grid, blk, 0, st, md, c->tp, t, seed, c->x_trace + (size_t)(t - 1) * row, lw_prev, ref_dev + (size_t)t * nx, 1,
                                c->aux_buf, c->sb[0]);
             KCHK(c, "k_front");
-            rc = launch_upper(c, c->sb[0], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
+            rc = launch_groups(c, c->sb[0], 2, st);
+            if (rc) return rc;
+            rc = launch_count(c, c->sb[0], 0, 0, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), st);
             if (rc) return rc;
             hipLaunchKernelGGL(c->back_corrected, grid, blk, 0, st, md, c->tp, t, seed, pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t),
-                               c->aux_buf, ref_dev + (size_t)t * nx, c->sb[0], c->anc_trace + (size_t)(t - 1) * N, c->x_trace + (size_t)t * row, lw_out);
+                               c->aux_buf, ref_dev + (size_t)t * nx, c->sb[0], pr, c->anc_trace + (size_t)(t - 1) * N, c->x_trace + (size_t)t * row, lw_out);
             KCHK(c, "k_back_corrected");
         }
         if (c->logw_trace)
             HIPCHK(c, hipMemcpyAsync(c->logw_last, c->logw_trace + (size_t)(T - 1) * N, N * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else {
-        const size_t np = (size_t)md.nseg * PGAS_SEG;
-        if (c->profiling) {
-            if ((int)c->ev.size() < 2 * T) {
-                const size_t old = c->ev.size();
-                c->ev.resize(2 * (size_t)T);
-                for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
-            }
-        }
-        // pipeline A (caller's stream): every particle through all time steps; independent of the weights (quirk Q1).
-        // pipeline B (internal stream when overlap is on): the weight recursion, gated chunk by chunk on
-        // pipeline A by events, so that its latency-bound launches run underneath k_propagate's arithmetic.
-        // default chunk, measured (tools/overlap_exp.sh, tools/config_times.py): one step per launch for the cheap 1-D / 2-D bases,
-        // 16 for the 3-D bases whose k_propagate launches are ten times longer than a k_resample launch
+        // default chunk, measured (tools/overlap_exp.sh, tools/config_times.py): one step per k_propagate launch for the cheap 1-D / 2-D
+        // bases, 16 for the 3-D bases whose k_propagate launches are ten times longer than a k_step launch
         const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? (md.D >= 3 ? 16 : 1) : T);
-        const int nchunk = (T - 1 + chunk - 1) / chunk;
-        hipStream_t sb_stream = st;
-        if (c->overlap) {
-            if (!c->sB) {
-                int lo = 0, hi = 0;
-                HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-                // measured (tools/overlap_exp.sh): the chain stream at LOW priority and one-step k_propagate launches overlap best
-                HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, lo));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
-                HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-            }
-            while ((int)c->ev_chunk.size() < nchunk) {
-                hipEvent_t e;
-                HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                c->ev_chunk.push_back(e);
-            }
-            sb_stream = c->sB;
-            HIPCHK(c, hipEventRecord(c->ev_start, st));
-            HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_start, 0));
-        }
-        const bool fast = md.nseg <= PG_FAST_NSEG && !c->force_slow;
-        // launches are issued chunk by chunk, pipeline A first, so both device queues stay fed
-        for (int ci = 0; ci < nchunk; ++ci) {
-            const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
-            const bool ptimed = c->profiling && (ci % c->prof_stride) == 0;
-            if (ptimed) {
-                while ((int)c->evp.size() < c->evp_used + 2) {
-                    hipEvent_t e;
-                    HIPCHK(c, hipEventCreate(&e));
-                    c->evp.push_back(e);
-                }
-                // start/stop events bound to the dispatch itself: they carry the kernel's own begin/end timestamps
-                hipExtLaunchKernelGGL(c->var.prop, grid, blk, c->overlap ? c->prop_lds : 0, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, md, c->tp, seed,
-                                      t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
-                c->evp_used += 2;
-            } else {
-                hipLaunchKernelGGL(c->var.prop, grid, blk, c->overlap ? c->prop_lds : 0, st, md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
-            }
-            KCHK(c, "k_propagate");
-            if (c->overlap) {
-                HIPCHK(c, hipEventRecord(c->ev_chunk[ci], st));
-                HIPCHK(c, hipStreamWaitEvent(c->sB, c->ev_chunk[ci], 0));
-            }
-            // launch t resamples step t-1 (t > 1) and scans step t (t < T); the last chunk also runs launch T
-            const int tend = ci == nchunk - 1 ? T + 1 : t1;
-            for (int t = t0; t < tend; ++t) {
-                ScanBufs sp = c->sb[(t - 1) & 1], sn = c->sb[t & 1];
-                sp.laux = c->la_buf + (size_t)(t - 1) * np;
-                sn.laux = c->la_buf + (size_t)(t < T ? t : T - 1) * np;
-                const int mode = (t < T ? PG_RS_SCAN : 0) | (t > 1 ? PG_RS_SEARCH : 0);
-                const double u1p = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)) : 0.0;
-                const double u2p = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)(t - 1)) : 0.0;
-                const double* la_t = t < T ? c->la_buf + (size_t)t * np : (const double*)nullptr;
-                const double* h_t = t < T ? c->h_buf + (size_t)t * np : (const double*)nullptr;
-                int32_t* anc = t > 1 ? c->anc_trace + (size_t)(t - 2) * N : (int32_t*)nullptr;
-                double* lwo = t == T ? c->logw_last : ((c->logw_trace && t > 1) ? c->logw_trace + (size_t)(t - 1) * N : (double*)nullptr);
-                const bool timed = c->profiling && t < T && (t % c->prof_stride) == 0;
-                hipEvent_t e0 = timed ? c->ev[c->ev_used] : (hipEvent_t) nullptr, e1 = timed ? c->ev[c->ev_used + 1] : (hipEvent_t) nullptr;
-                if (timed) c->ev_used += 2;
-                if (fast) {
-                    AncInputs ai;   // what the ancestor workgroup needs to rebuild one segment of the ancestor CDF of step s = t - 1
-                    ai.la_s = sp.laux;
-                    ai.h_s = c->h_buf + (size_t)(t > 1 ? t - 1 : 0) * np;
-                    ai.ln_p = t > 2 ? c->ln_buf + (size_t)(t - 2) * np : (const double*)nullptr;
-                    ai.la_p = t > 2 ? c->la_buf + (size_t)(t - 2) * np : (const double*)nullptr;
-                    ai.anc_p = t > 2 ? c->anc_trace + (size_t)(t - 3) * N : (const int32_t*)nullptr;
-                    ai.kref = sp.segm + sp.nsegp;
-                    hipExtLaunchKernelGGL(k_resample_fast, dim3(md.nseg + 1), blk, 0, sb_stream, e0, e1, 0, md, t, mode, ++c->launch_tag, u1p, u2p, ai, la_t,
-                                          h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn, anc, lwo);
-                    KCHK(c, "k_resample_fast");
-                } else {
-                    hipExtLaunchKernelGGL(k_resample, grid, blk, 0, sb_stream, e0, e1, 0, md, t, mode, u1p, la_t, h_t, c->ln_buf + (size_t)(t - 1) * np, sp, sn,
-                                          c->peers, (int64_t)((size_t)(t - 1) * np), anc, lwo);
-                    KCHK(c, "k_resample");
-                }
-                if (!fast && t < T) {
-                    rc = launch_upper(c, sn, 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, sb_stream);
-                    if (rc) return rc;
-                }
-            }
-        }
-        if (c->overlap) {
-            HIPCHK(c, hipEventRecord(c->ev_done, c->sB));
-            HIPCHK(c, hipStreamWaitEvent(st, c->ev_done, 0));
-        }
+        c->last_chunk = chunk;
+        rc = run_time_loop(c, seed, ref_dev, chunk, st);
+        if (rc) return rc;
         if (c->logw_trace)
             HIPCHK(c, hipMemcpyAsync(c->logw_trace + (size_t)(T - 1) * N, c->logw_last, N * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
-    // final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
-    ScanBufs& sf = c->sb[T & 1];
-    hipLaunchKernelGGL(k_segscan, grid, blk, 0, st, N, c->logw_last, sf);
-    KCHK(c, "k_segscan");
-    rc = launch_upper(c, sf, 1, 0, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), 1, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, st, N, T, nx, c->x_trace, c->anc_trace, c->peers, sf.hdr, traj_dev);
-    KCHK(c, "k_backtrace");
-    return PGAS_OK;
+    return run_final(c, seed, traj_dev, st);
 }
 
 int pgas_get_traces(pgas_ctx* c, double** x_trace, int32_t** anc_trace, double** logw_last, double** logw_trace) {
@@ -612,7 +724,7 @@ int pgas_last_final_index(pgas_ctx* c, int64_t* idx, void* stream) {
     if (!c) return PGAS_E_ARG;
     if (!idx) FAIL(c, PGAS_E_ARG, "pgas_last_final_index: NULL argument");
     if (!c->x_trace) FAIL(c, PGAS_E_STATE, "pgas_last_final_index: no sweep has run");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
     UpperHdr h;
     HIPCHK(c, hipMemcpy(&h, c->sb[c->md.T & 1].hdr, sizeof h, hipMemcpyDeviceToHost));
@@ -663,7 +775,7 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
 int pgas_get_profile(pgas_ctx* c, int64_t* launches, double* total_ms, int64_t* propagate_launches, double* propagate_ms, void* stream) {
     if (!c) return PGAS_E_ARG;
     if (!launches || !total_ms || !propagate_launches || !propagate_ms) FAIL(c, PGAS_E_ARG, "pgas_get_profile: NULL argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
     double sum = 0.0;
     for (int i = 0; i + 1 < c->ev_used; i += 2) {
@@ -684,6 +796,20 @@ int pgas_get_profile(pgas_ctx* c, int64_t* launches, double* total_ms, int64_t* 
     return PGAS_OK;
 }
 
+/* What the last sweep actually launched (bench.py labels its roofline block from this, not from constants):
+ * info[0] = time steps per k_propagate launch, info[1] = 1 when k_step scanned the groups itself (single device, <= 1024
+ * segments), 0 when k_groups ran between the steps, info[2] = padded innermost basis extent JP of the k_propagate variant,
+ * info[3] = particles per basis pass P of that variant. */
+int pgas_get_launch_info(pgas_ctx* c, int32_t* info4) {
+    if (!c) return PGAS_E_ARG;
+    if (!info4) FAIL(c, PGAS_E_ARG, "pgas_get_launch_info: NULL argument");
+    info4[0] = c->last_chunk;
+    info4[1] = sweep_is_local(c) ? 1 : 0;
+    info4[2] = c->md.JP;
+    info4[3] = c->var_P;
+    return PGAS_OK;
+}
+
 #ifdef PG_STAMPS
 int pgas_debug_stamps(unsigned long long* out /* 2048*16 */) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 2048 * 16) == hipSuccess ? 0 : -2;
@@ -697,14 +823,15 @@ int pgas_systematic_resample(pgas_ctx* c, double u, const double* logw_dev, int3
     if (!c) return PGAS_E_ARG;
     if (!logw_dev || !idx_dev || !(u >= 0.0 && u < 1.0)) FAIL(c, PGAS_E_ARG, "pgas_systematic_resample: bad argument");
     if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_systematic_resample: not available on a shard context");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
     const DevModel& md = c->md;
+    install_own_peers(c);
     hipLaunchKernelGGL(k_segscan, dim3(md.nseg), dim3(PG_BLK), 0, st, md.N, logw_dev, c->sb[0]);
     KCHK(c, "k_segscan");
-    int rc = launch_upper(c, c->sb[0], 1, -1, 0.0, 0, st);
+    int rc = launch_groups(c, c->sb[0], 1, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_systematic, dim3(md.nseg), dim3(PG_BLK), 0, st, md, u, c->sb[0], idx_dev);
+    hipLaunchKernelGGL(k_systematic, dim3(md.nseg), dim3(PG_BLK), 0, st, md, u, c->sb[0], peers_for(c, 0), idx_dev);
     KCHK(c, "k_systematic");
     return PGAS_OK;
 }
@@ -716,7 +843,7 @@ int pgas_reconstruct_trajectory(pgas_ctx* c, const double* x_dev, const int32_t*
     if (!c) return PGAS_E_ARG;
     if (!x_dev || !traj_dev || T < 1 || nx < 1 || idx < 0 || idx >= c->md.N || (T > 1 && !anc_dev))
         FAIL(c, PGAS_E_ARG, "pgas_reconstruct_trajectory: bad argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipLaunchKernelGGL(k_backtrace_idx, dim3(1), dim3(64), 0, (hipStream_t)stream, c->md.N, T, nx, x_dev, anc_dev, idx, traj_dev);
     KCHK(c, "k_backtrace_idx");
     return PGAS_OK;
@@ -724,9 +851,9 @@ int pgas_reconstruct_trajectory(pgas_ctx* c, const double* x_dev, const int32_t*
 
 // ------------------------------------------------------------------------------------------------
 // Particle-sharded sweep (one context per rank, each owning N_local = N_global / world particles).
-// The host (pgas_amd/sharded.py) drives the phases and performs the one collective per step -- an
-// all-gather of the per-segment softmax partials -- with torch.distributed (RCCL); peers' scan buffers
-// are read directly through xGMI peer mappings whose pointers are installed with pgas_shard_set_peer.
+// Per time step: k_step (local search + scans), ONE collective -- an all-gather of the per-segment softmax partials --,
+// k_groups over the gathered partials (every rank computes the same group records); peers' cumsums, log-likelihood rows
+// and traces are read directly through xGMI peer mappings whose pointers are installed with pgas_shard_set_peer.
 // ------------------------------------------------------------------------------------------------
 int pgas_shard_setup(pgas_ctx* c, int32_t rank, int32_t world) {
     if (!c) return PGAS_E_ARG;
@@ -734,78 +861,100 @@ int pgas_shard_setup(pgas_ctx* c, int32_t rank, int32_t world) {
     if (c->md.N % PGAS_SEG) FAIL(c, PGAS_E_ARG, "pgas_shard_setup: local particle count %d must be a multiple of %d", c->md.N, PGAS_SEG);
     if ((int64_t)c->md.nseg * world > PG_MAX_NSEG) FAIL(c, PGAS_E_ARG, "pgas_shard_setup: %d global segments exceed %d", c->md.nseg * world, PG_MAX_NSEG);
     if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_setup: already set up");
-    HIPCHK(c, hipSetDevice(c->device));
+    if (c->corrected) FAIL(c, PGAS_E_STATE, "pgas_shard_setup: the corrected mode is not available on a sharded context");
+    DeviceGuard guard(c->device);
     int rc = ensure_traces(c);
     if (rc) return rc;
+    // allocate everything first, commit the context's state only when nothing can fail any more
+    const int nsegp = c->sb[0].nsegp, nseg_g = c->md.nseg * world, nsegp_g = (nseg_g + 63) / 64 * 64;
+    double* segk_g[2] = {nullptr, nullptr};
+    uint64_t* segs_g[2] = {nullptr, nullptr};
+    double* tab[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc(&segk_g[i], (size_t)world * 2 * nsegp * sizeof(double));
+        if (e == hipSuccess) e = hipMalloc(&segs_g[i], (size_t)world * 2 * nsegp * sizeof(uint64_t));
+        for (int k = 0; k < 3 && e == hipSuccess; ++k) e = hipMalloc(&tab[i][k], 2 * (size_t)nsegp_g * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(segk_g[i], 0, (size_t)world * 2 * nsegp * sizeof(double));
+        if (e == hipSuccess) e = hipMemset(segs_g[i], 0, (size_t)world * 2 * nsegp * sizeof(uint64_t));
+    }
+    if (e != hipSuccess) {
+        for (int i = 0; i < 2; ++i) {
+            hipFree(segk_g[i]); hipFree(segs_g[i]);
+            for (int k = 0; k < 3; ++k) hipFree(tab[i][k]);
+        }
+        FAIL(c, e == hipErrorOutOfMemory ? PGAS_E_NOMEM : PGAS_E_HIP, "pgas_shard_setup: allocation failed: %s", hipGetErrorString(e));
+    }
     DevModel& md = c->md;
     c->rank = rank; c->world = world;
     md.p0 = (int64_t)rank * md.N;
     md.Ng = md.N * world;
-    md.nseg_g = md.nseg * world;
+    md.nseg_g = nseg_g;
+    for (int r = 0; r < PG_MAX_RANKS; ++r) {   // forget the single-device table: every rank must be installed again
+        c->peers.la[r] = c->peers.h[r] = c->peers.ln[r] = c->peers.x[r] = nullptr;
+        c->peers.anc[r] = nullptr;
+        c->peer_c1[0][r] = c->peer_c1[1][r] = c->peer_c2[0][r] = c->peer_c2[1][r] = nullptr;
+    }
     c->peers.world = world; c->peers.nseg_l = md.nseg; c->peers.Nl = md.N;
-    const int nsegp = c->sb[0].nsegp, nsegp_g = (md.nseg_g + 63) / 64 * 64;
     for (int i = 0; i < 2; ++i) {
         ScanBufs& sb = c->sb[i];
-        HIPCHK(c, hipMalloc(&c->segm_g[i], (size_t)world * 2 * nsegp * sizeof(double)));
-        HIPCHK(c, hipMalloc(&c->segs_g[i], (size_t)world * 2 * nsegp * sizeof(uint64_t)));
-        HIPCHK(c, hipMemset(c->segm_g[i], 0, (size_t)world * 2 * nsegp * sizeof(double)));
-        HIPCHK(c, hipMemset(c->segs_g[i], 0, (size_t)world * 2 * nsegp * sizeof(uint64_t)));
-        sb.segm_w = sb.segm; sb.segs_w = sb.segs;          // local scans keep writing their own (2, nsegp) block
-        sb.segm = c->segm_g[i]; sb.segs = c->segs_g[i];    // the cross-segment scan reads the gathered (world, 2, nsegp)
+        c->segk_g[i] = segk_g[i]; c->segs_g[i] = segs_g[i];
+        sb.segk = segk_g[i]; sb.segs = segs_g[i];          // group scans read the gathered (world, 2, nsegp); local scans keep writing segk_w/segs_w
         sb.nseg_l = md.nseg; sb.rank_stride = 2 * nsegp; sb.nsegp_g = nsegp_g;
-        hipFree(sb.excl); hipFree(sb.scale); hipFree(sb.cm);
-        HIPCHK(c, hipMalloc(&sb.excl, 2 * (size_t)nsegp_g * sizeof(double)));
-        HIPCHK(c, hipMalloc(&sb.scale, 2 * (size_t)nsegp_g * sizeof(double)));
-        HIPCHK(c, hipMalloc(&sb.cm, 2 * (size_t)nsegp_g * sizeof(double)));
-        c->peer_c1[i][rank] = sb.c1; c->peer_c2[i][rank] = sb.c2;
+        hipFree(sb.tab_e); hipFree(sb.tab_sc); hipFree(sb.tab_m);
+        sb.tab_e = tab[i][0]; sb.tab_sc = tab[i][1]; sb.tab_m = tab[i][2];
     }
-    c->peers.laux[rank] = c->la_buf; c->peers.x[rank] = c->x_trace; c->peers.anc[rank] = c->anc_trace;
     c->sharded = true;
+    install_own_peers(c);
     return PGAS_OK;
 }
 
-/* out[15]: c1[0], c1[1], c2[0], c2[1], la_buf, x_trace, anc_trace, segm_w[0], segm_w[1], segs_w[0], segs_w[1],
- *          segm_g[0], segm_g[1], segs_g[0], segs_g[1]; sizes[3]: nsegp (local padded segments), N_local, T */
+/* out[17]: c1[0], c1[1], la_buf, h_buf, ln_buf, x_trace, anc_trace (the seven buffers peers read; pgas_ipc_export indices),
+ *          c2[0], c2[1] (unused by the sweep), segk_w[0], segk_w[1], segs_w[0], segs_w[1], segk_g[0], segk_g[1], segs_g[0], segs_g[1];
+ * sizes[3]: nsegp (local padded segments), N_local, T */
 int pgas_shard_buffers(pgas_ctx* c, void** out, int64_t* sizes) {
     if (!c) return PGAS_E_ARG;
     if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_buffers: call pgas_shard_setup first");
     if (!out || !sizes) FAIL(c, PGAS_E_ARG, "pgas_shard_buffers: NULL argument");
-    out[0] = c->sb[0].c1; out[1] = c->sb[1].c1; out[2] = c->sb[0].c2; out[3] = c->sb[1].c2;
-    out[4] = c->la_buf; out[5] = c->x_trace; out[6] = c->anc_trace;
-    out[7] = c->sb[0].segm_w; out[8] = c->sb[1].segm_w; out[9] = c->sb[0].segs_w; out[10] = c->sb[1].segs_w;
-    out[11] = c->segm_g[0]; out[12] = c->segm_g[1]; out[13] = c->segs_g[0]; out[14] = c->segs_g[1];
+    out[0] = c->sb[0].c1; out[1] = c->sb[1].c1; out[2] = c->la_buf; out[3] = c->h_buf; out[4] = c->ln_buf; out[5] = c->x_trace; out[6] = c->anc_trace;
+    out[7] = c->sb[0].c2; out[8] = c->sb[1].c2;
+    out[9] = c->sb[0].segk_w; out[10] = c->sb[1].segk_w; out[11] = c->sb[0].segs_w; out[12] = c->sb[1].segs_w;
+    out[13] = c->segk_g[0]; out[14] = c->segk_g[1]; out[15] = c->segs_g[0]; out[16] = c->segs_g[1];
     sizes[0] = c->sb[0].nsegp; sizes[1] = c->md.N; sizes[2] = c->md.T;
     return PGAS_OK;
 }
 
-/* bufs[7]: the peer's c1[0], c1[1], c2[0], c2[1], la_buf, x_trace, anc_trace as mapped into THIS process */
+/* bufs[7]: the peer's c1[0], c1[1], la_buf, h_buf, ln_buf, x_trace, anc_trace as mapped into THIS process */
 int pgas_shard_set_peer(pgas_ctx* c, int32_t peer, const void* const* bufs) {
     if (!c) return PGAS_E_ARG;
     if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_set_peer: call pgas_shard_setup first");
     if (peer < 0 || peer >= c->world || !bufs) FAIL(c, PGAS_E_ARG, "pgas_shard_set_peer: bad argument");
+    for (int k = 0; k < 7; ++k)
+        if (!bufs[k]) FAIL(c, PGAS_E_ARG, "pgas_shard_set_peer: buffer %d of rank %d is NULL", k, peer);
     c->peer_c1[0][peer] = (const uint64_t*)bufs[0]; c->peer_c1[1][peer] = (const uint64_t*)bufs[1];
-    c->peer_c2[0][peer] = (const uint64_t*)bufs[2]; c->peer_c2[1][peer] = (const uint64_t*)bufs[3];
-    c->peers.laux[peer] = (const double*)bufs[4]; c->peers.x[peer] = (const double*)bufs[5]; c->peers.anc[peer] = (const int32_t*)bufs[6];
+    c->peers.la[peer] = (const double*)bufs[2]; c->peers.h[peer] = (const double*)bufs[3]; c->peers.ln[peer] = (const double*)bufs[4];
+    c->peers.x[peer] = (const double*)bufs[5]; c->peers.anc[peer] = (const int32_t*)bufs[6];
+    return PGAS_OK;
+}
+
+static int shard_ready(pgas_ctx* c, const char* who) {
+    if (!c->sharded) FAIL(c, PGAS_E_STATE, "%s: call pgas_shard_setup first", who);
+    if (!c->have_params) FAIL(c, PGAS_E_STATE, "%s: call pgas_set_params first", who);
+    for (int r = 0; r < c->world; ++r)
+        if (!c->peers.la[r] || !c->peers.h[r] || !c->peers.ln[r] || !c->peers.x[r] || !c->peers.anc[r] || !c->peer_c1[0][r] || !c->peer_c1[1][r])
+            FAIL(c, PGAS_E_STATE, "%s: buffers of rank %d not installed (pgas_shard_set_peer)", who, r);
     return PGAS_OK;
 }
 
 int pgas_shard_run(pgas_ctx* c, int32_t phase, int32_t t, int32_t t_aux, uint64_t seed, const double* ref_dev, double* traj_dev, void* stream) {
     if (!c) return PGAS_E_ARG;
-    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_run: call pgas_shard_setup first");
-    if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_shard_run: call pgas_set_params first");
-    HIPCHK(c, hipSetDevice(c->device));
+    int rc = shard_ready(c, "pgas_shard_run");
+    if (rc) return rc;
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
     const DevModel& md = c->md;
     const int N = md.N, T = md.T;
     const dim3 grid(md.nseg), blk(PG_BLK);
-    const size_t np = (size_t)md.nseg * PGAS_SEG;
-    for (int r = 0; r < c->world; ++r)
-        if (!c->peers.laux[r] || !c->peer_c1[0][r]) FAIL(c, PGAS_E_STATE, "pgas_shard_run: buffers of rank %d not installed", r);
-    auto peers_for = [&](int parity) {
-        Peers p = c->peers;
-        for (int r = 0; r < c->world; ++r) { p.c1[r] = c->peer_c1[parity][r]; p.c2[r] = c->peer_c2[parity][r]; }
-        return p;
-    };
     switch (phase) {
     case PGAS_SHARD_INIT:
         if (!ref_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_run(INIT): ref_dev == NULL");
@@ -814,41 +963,21 @@ int pgas_shard_run(pgas_ctx* c, int32_t phase, int32_t t, int32_t t_aux, uint64_
         return PGAS_OK;
     case PGAS_SHARD_PROPAGATE:  // time steps [t, t_aux)
         if (!ref_dev || t < 1 || t_aux > T || t >= t_aux) FAIL(c, PGAS_E_ARG, "pgas_shard_run(PROPAGATE): bad range [%d,%d)", t, t_aux);
-        hipLaunchKernelGGL(c->var.prop, grid, blk, 0, st, md, c->tp, seed, t, t_aux, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
-        KCHK(c, "k_propagate");
-        return PGAS_OK;
-    case PGAS_SHARD_RESAMPLE: {  // launch t in [1, T]: resample step t-1 (t > 1), scan step t (t < T)
-        if (t < 1 || t > T) FAIL(c, PGAS_E_ARG, "pgas_shard_run(RESAMPLE): t = %d outside [1, %d]", t, T);
-        ScanBufs sp = c->sb[(t - 1) & 1], sn = c->sb[t & 1];
-        sp.laux = c->la_buf + (size_t)(t - 1) * np;
-        sn.laux = c->la_buf + (size_t)(t < T ? t : T - 1) * np;
-        const int mode = (t < T ? PG_RS_SCAN : 0) | (t > 1 ? PG_RS_SEARCH : 0);
-        hipLaunchKernelGGL(k_resample, grid, blk, 0, st, md, t, mode, t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)) : 0.0,
-                           t < T ? c->la_buf + (size_t)t * np : (const double*)nullptr, t < T ? c->h_buf + (size_t)t * np : (const double*)nullptr,
-                           c->ln_buf + (size_t)(t - 1) * np, sp, sn, peers_for((t - 1) & 1), (int64_t)((size_t)(t - 1) * np),
-                           t > 1 ? c->anc_trace + (size_t)(t - 2) * N : (int32_t*)nullptr, t == T ? c->logw_last : (double*)nullptr);
-        KCHK(c, "k_resample");
-        return PGAS_OK;
-    }
-    case PGAS_SHARD_UPPER: {  // after the all-gather of step t's partials
-        if (t < 1 || t >= T) FAIL(c, PGAS_E_ARG, "pgas_shard_run(UPPER): t = %d outside [1, %d)", t, T);
-        Peers keep = c->peers;
-        c->peers = peers_for(t & 1);
-        int rc = launch_upper(c, c->sb[t & 1], 2, 1, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), 0, st);
-        c->peers = keep;
-        return rc;
-    }
+        return launch_propagate(c, seed, t, t_aux, ref_dev, st, false);
+    case PGAS_SHARD_STEP:  // launch t in [1, T]: resample step t-1 (t > 1), scan step t (t < T)
+        if (t < 1 || t > T) FAIL(c, PGAS_E_ARG, "pgas_shard_run(STEP): t = %d outside [1, %d]", t, T);
+        return launch_step(c, t, seed, false, st, nullptr, nullptr);
+    case PGAS_SHARD_GROUPS:  // after the all-gather of step t's partials
+        if (t < 1 || t >= T) FAIL(c, PGAS_E_ARG, "pgas_shard_run(GROUPS): t = %d outside [1, %d)", t, T);
+        return launch_groups(c, c->sb[t & 1], 2, st);
     case PGAS_SHARD_FINAL_SCAN:
         hipLaunchKernelGGL(k_segscan, grid, blk, 0, st, N, c->logw_last, c->sb[T & 1]);
         KCHK(c, "k_segscan");
         return PGAS_OK;
-    case PGAS_SHARD_FINAL_UPPER: {
-        Peers keep = c->peers;
-        c->peers = peers_for(T & 1);
-        int rc = launch_upper(c, c->sb[T & 1], 1, 0, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), 1, st);
-        c->peers = keep;
-        return rc;
-    }
+    case PGAS_SHARD_FINAL:  // after the all-gather of the final scan's partials: final index (src/PGAS.py:224-225)
+        rc = launch_groups(c, c->sb[T & 1], 1, st);
+        if (rc) return rc;
+        return launch_count(c, c->sb[T & 1], T & 1, 1, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), st);
     case PGAS_SHARD_BACKTRACE:
         if (!traj_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_run(BACKTRACE): traj_dev == NULL");
         hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, st, N, T, md.nx, c->x_trace, c->anc_trace, c->peers, c->sb[T & 1].hdr, traj_dev);
@@ -877,7 +1006,7 @@ int pgas_shard_comm_init(pgas_ctx* c, const void* id128) {
     if (!id128) FAIL(c, PGAS_E_ARG, "pgas_shard_comm_init: NULL id");
     if (!rccl().ok) FAIL(c, PGAS_E_STATE, "pgas_shard_comm_init: librccl.so could not be loaded");
     if (c->comm) return PGAS_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
     NCCLCHK(c, rccl().init_rank(&c->comm, c->world, id, c->rank));
@@ -886,11 +1015,30 @@ int pgas_shard_comm_init(pgas_ctx* c, const void* id128) {
     return PGAS_OK;
 }
 
-// one collective: the (2, nsegp) partials of every rank -> (world, 2, nsegp), both arrays in one RCCL group
+int pgas_shard_set_collective(pgas_ctx* c, pgas_allgather_fn fn, void* user) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_set_collective: call pgas_shard_setup first");
+    c->ag_cb = fn;
+    c->ag_user = user;
+    return PGAS_OK;
+}
+
 static int shard_all_gather(pgas_ctx* c, int parity, hipStream_t st) {
     const size_t cnt = 2 * (size_t)c->sb[parity].nsegp;
+    if (c->ag_cb) {
+        // host-staged collective (tests: several ranks on one device, where RCCL refuses duplicate devices).  parity < 0 asks for
+        // the end-of-sweep barrier.  The callback synchronises the stream itself.
+        const int rc = c->ag_cb(c->ag_user, parity, (void*)st);
+        if (rc) FAIL(c, PGAS_E_HIP, "all-gather callback failed (%d)", rc);
+        return PGAS_OK;
+    }
+    if (!c->comm) FAIL(c, PGAS_E_STATE, "sharded sweep: call pgas_shard_comm_init (RCCL) or pgas_shard_set_collective first");
+    if (parity < 0) {
+        NCCLCHK(c, rccl().all_gather(c->d_sync + c->world, c->d_sync, 1, ncclInt32, c->comm, st));
+        return PGAS_OK;
+    }
     NCCLCHK(c, rccl().group_start());
-    NCCLCHK(c, rccl().all_gather(c->sb[parity].segm_w, c->segm_g[parity], cnt, ncclDouble, c->comm, st));
+    NCCLCHK(c, rccl().all_gather(c->sb[parity].segk_w, c->segk_g[parity], cnt, ncclDouble, c->comm, st));
     NCCLCHK(c, rccl().all_gather(c->sb[parity].segs_w, c->segs_g[parity], cnt, ncclUint64, c->comm, st));
     NCCLCHK(c, rccl().group_end());
     return PGAS_OK;
@@ -898,92 +1046,49 @@ static int shard_all_gather(pgas_ctx* c, int parity, hipStream_t st) {
 
 int pgas_shard_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_dev, int32_t propagate_chunk, void* stream) {
     if (!c) return PGAS_E_ARG;
-    if (!c->sharded || !c->comm) FAIL(c, PGAS_E_STATE, "pgas_shard_sweep: call pgas_shard_setup and pgas_shard_comm_init first");
+    int rc = shard_ready(c, "pgas_shard_sweep");
+    if (rc) return rc;
+    if (!c->comm && !c->ag_cb) FAIL(c, PGAS_E_STATE, "pgas_shard_sweep: call pgas_shard_comm_init (RCCL) or pgas_shard_set_collective first");
     if (!ref_dev || !traj_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_sweep: NULL argument");
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
-    const int T = c->md.T;
-    int rc = pgas_shard_run(c, PGAS_SHARD_INIT, 0, 0, seed, ref_dev, nullptr, stream);
-    if (rc) return rc;
-    // pipeline A (k_propagate, caller's stream) runs ahead chunk by chunk; pipeline B (resample, all-gather, cross-segment scan)
-    // follows on the internal stream, gated by one event per chunk -- as in pgas_sweep
-    const int chunk = propagate_chunk > 0 ? propagate_chunk : (c->overlap ? 16 : T);
-    const int nchunk = T > 1 ? (T - 1 + chunk - 1) / chunk : 0;
-    hipStream_t sb = st;
-    if (c->overlap && T > 1) {
-        if (!c->sB) {
-            int lo = 0, hi = 0;
-            HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-            HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, lo));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
-        }
-        while ((int)c->ev_chunk.size() < nchunk) {
-            hipEvent_t e;
-            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            c->ev_chunk.push_back(e);
-        }
-        sb = c->sB;
-        HIPCHK(c, hipEventRecord(c->ev_start, st));
-        HIPCHK(c, hipStreamWaitEvent(sb, c->ev_start, 0));
-    }
-    for (int ci = 0; ci < nchunk; ++ci) {
-        const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
-        rc = pgas_shard_run(c, PGAS_SHARD_PROPAGATE, t0, t1, seed, ref_dev, nullptr, st);
-        if (rc) return rc;
-        if (sb != st) {
-            HIPCHK(c, hipEventRecord(c->ev_chunk[ci], st));
-            HIPCHK(c, hipStreamWaitEvent(sb, c->ev_chunk[ci], 0));
-        }
-        const int tend = ci == nchunk - 1 ? T + 1 : t1;   // the last chunk also runs launch T
-        for (int t = t0; t < tend; ++t) {
-            rc = pgas_shard_run(c, PGAS_SHARD_RESAMPLE, t, 0, seed, nullptr, nullptr, sb);
-            if (rc) return rc;
-            if (t < T) {
-                rc = shard_all_gather(c, t & 1, sb);   // the one collective of the step (RCCL over xGMI), stream-ordered: no host round trip
-                if (rc) return rc;
-                rc = pgas_shard_run(c, PGAS_SHARD_UPPER, t, 0, seed, nullptr, nullptr, sb);
-                if (rc) return rc;
-            }
-        }
-    }
+    const DevModel& md = c->md;
+    const int T = md.T;
+    hipLaunchKernelGGL(c->init, dim3((md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, md, seed, c->d_m0L0, ref_dev, c->x_trace);
+    KCHK(c, "k_init");
+    c->ev_used = 0;
+    c->evp_used = 0;
     if (T == 1) {
-        rc = pgas_shard_run(c, PGAS_SHARD_RESAMPLE, 1, 0, seed, nullptr, nullptr, sb);
+        HIPCHK(c, hipMemsetAsync(c->logw_last, 0, md.N * sizeof(double), st));
+    } else {
+        const int chunk = propagate_chunk > 0 ? propagate_chunk : (c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? (md.D >= 3 ? 16 : 1) : T));
+        c->last_chunk = chunk;
+        rc = run_time_loop(c, seed, ref_dev, chunk, st);
         if (rc) return rc;
     }
-    if (sb != st) {
-        HIPCHK(c, hipEventRecord(c->ev_done, sb));
-        HIPCHK(c, hipStreamWaitEvent(st, c->ev_done, 0));
-    }
-    rc = pgas_shard_run(c, PGAS_SHARD_FINAL_SCAN, 0, 0, seed, nullptr, nullptr, stream);
-    if (rc) return rc;
-    rc = shard_all_gather(c, T & 1, st);
-    if (rc) return rc;
-    rc = pgas_shard_run(c, PGAS_SHARD_FINAL_UPPER, 0, 0, seed, nullptr, nullptr, stream);
-    if (rc) return rc;
-    rc = pgas_shard_run(c, PGAS_SHARD_BACKTRACE, 0, 0, seed, nullptr, traj_dev, stream);
+    rc = run_final(c, seed, traj_dev, st);
     if (rc) return rc;
     // peers may still be chasing ancestors through this rank's traces: one more (tiny) collective closes the sweep on every rank
-    NCCLCHK(c, rccl().all_gather(c->d_sync + c->world, c->d_sync, 1, ncclInt32, c->comm, st));
-    return PGAS_OK;
+    return shard_all_gather(c, -1, st);
 }
 
 /* xGMI / IPC plumbing for peers in OTHER processes: export a 64-byte handle of one of this context's buffers
  * (index as in pgas_shard_buffers, 0..6) and map a peer's handle into this process. */
 int pgas_ipc_export(pgas_ctx* c, int32_t which, void* handle64) {
     if (!c) return PGAS_E_ARG;
-    void* bufs[15]; int64_t sz[3];
+    void* bufs[17]; int64_t sz[3];
     int rc = pgas_shard_buffers(c, bufs, sz);
     if (rc) return rc;
     if (which < 0 || which > 6 || !handle64) FAIL(c, PGAS_E_ARG, "pgas_ipc_export: bad argument");
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     HIPCHK(c, hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, bufs[which]));
     return PGAS_OK;
 }
 int pgas_ipc_open(pgas_ctx* c, const void* handle64, void** ptr) {
     if (!c) return PGAS_E_ARG;
     if (!handle64 || !ptr) FAIL(c, PGAS_E_ARG, "pgas_ipc_open: NULL argument");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipIpcMemHandle_t h;
     memcpy(&h, handle64, sizeof h);
     HIPCHK(c, hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
@@ -995,7 +1100,7 @@ int pgas_suffstats(pgas_ctx* c, const double* traj_dev, double* T0_dev, double* 
     if (!traj_dev || !T0_dev || !T1_dev || !T2_dev) FAIL(c, PGAS_E_ARG, "pgas_suffstats: NULL argument");
     const DevModel& md = c->md;
     if (md.T < 2) FAIL(c, PGAS_E_ARG, "pgas_suffstats: needs T >= 2");
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
     const int R = md.T - 1;                         // rows: t = 0..T-2   (traj[:-1], inputs[:-1]; Q3)
     const int Mp = (md.M + 15) / 16 * 16;           // padded to the MFMA tile
@@ -1022,7 +1127,7 @@ int pgas_m_rng_normal(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t, i
     if (!c) return PGAS_E_ARG;
     if (!out || n < 0 || ncol < 1 || ncol > 8) FAIL(c, PGAS_E_ARG, "pgas_m_rng_normal: bad argument (n = %lld, ncol = %d)", (long long)n, ncol);
     if (n == 0) return PGAS_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipLaunchKernelGGL(k_rng_normal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, p0, n, ncol, out);
     KCHK(c, "k_rng_normal");
     return PGAS_OK;
@@ -1032,7 +1137,7 @@ int pgas_m_rng_student_t(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t
     if (!c) return PGAS_E_ARG;
     if (!out || !nu || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_rng_student_t: bad argument");
     if (n == 0) return PGAS_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipLaunchKernelGGL(k_rng_student_t, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, p0, n, nu, out);
     KCHK(c, "k_rng_student_t");
     return PGAS_OK;
@@ -1045,7 +1150,7 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
     if (M < 1 || M > PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: M = %d outside [1, %d]", M, PG_MN_MAXM);
     if ((R0 == nullptr) != (R1 == nullptr)) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: R0 and R1 must be given together");
     if (n == 0) return PGAS_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)sh;
     if (!c->d_fail) {
         HIPCHK(c, hipMalloc(&c->d_fail, sizeof(int32_t)));
@@ -1077,7 +1182,7 @@ int pgas_m_mniw_trisolve(pgas_ctx* c, int64_t n, int32_t M, const int32_t* anc, 
     if (!Lfac || !phi || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: NULL argument");
     if (M < 1 || M > PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: M = %d outside [1, %d]", M, PG_MN_MAXM);
     if (n == 0) return PGAS_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     const int waves = 4;
     hipLaunchKernelGGL(k_mniw_trisolve, dim3((unsigned)((n + waves - 1) / waves)), dim3(64 * waves),
                        (size_t)waves * ((M + 2) * (M + 3) / 2) * sizeof(double), (hipStream_t)sh, n, M, anc, Lfac, phi, m, cc);
@@ -1088,7 +1193,7 @@ int pgas_m_mniw_trisolve(pgas_ctx* c, int64_t n, int32_t M, const int32_t* anc, 
 int pgas_m_check(pgas_ctx* c, void* sh) {
     if (!c) return PGAS_E_ARG;
     if (!c->d_fail) return PGAS_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)sh;
     int32_t bad = 0;
     HIPCHK(c, hipMemcpyAsync(&bad, c->d_fail, sizeof bad, hipMemcpyDeviceToHost, st));
@@ -1106,7 +1211,7 @@ int pgas_m_stats_gather_update(pgas_ctx* c, int64_t n, int32_t M, double scale, 
     if (T0i == T0o || T1i == T1o || T2i == T2o || T3i == T3o) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: input and output alias");
     if (M < 1 || M > 2 * PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: M = %d outside [1, %d]", M, 2 * PG_MN_MAXM);
     if (n == 0) return PGAS_OK;
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipLaunchKernelGGL(k_stats_gather_update, dim3((unsigned)n), dim3(256), 0, (hipStream_t)sh, n, M, scale, anc, T0i, T1i, T2i, T3i, phi, xi, T0o, T1o, T2o, T3o);
     KCHK(c, "k_stats_gather_update");
     return PGAS_OK;
@@ -1117,7 +1222,7 @@ int pgas_m_weighted_stats(pgas_ctx* c, int64_t n, int32_t M, const double* w, co
     if (!c) return PGAS_E_ARG;
     if (!w || !T0 || !T1 || !T2 || !T3 || !S0 || !S1 || !S2 || !S3 || n < 1) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: bad argument");
     if (M < 1 || M > 2 * PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: M = %d outside [1, %d]", M, 2 * PG_MN_MAXM);
-    HIPCHK(c, hipSetDevice(c->device));
+    DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)sh;
     const int ncol = M * M + M + 2;
     const int64_t nchunk = (n + PG_WS_CHUNK - 1) / PG_WS_CHUNK;

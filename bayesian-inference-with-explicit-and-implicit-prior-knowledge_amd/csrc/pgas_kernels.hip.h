@@ -67,40 +67,42 @@ struct TransParams {   // transition parameters, by value
     const double* G;   // packed coefficient tensor
 };
 
-struct UpperHdr {      // written by k_upper
-    double S[2];
-    int32_t valid[2];
-    int32_t ref_idx;
-    int32_t final_idx;
-    unsigned long long ref_granule;  // k_resample_fast: {launch tag : 32, ancestor of the conditioned particle : 32}, one 8-byte store
+struct UpperHdr {      // small per-scan-buffer results
+    int32_t ref_idx;     // ancestor of the conditioned particle (k_count, step API)
+    int32_t final_idx;   // index of the final draw (k_count)
+    unsigned long long ref_granule;  // k_step: {launch tag : 32, ancestor of the conditioned particle : 32}, one 8-byte store
 };
 
 #define PG_MAX_RANKS 8
 struct Peers {         // device pointers of every rank's buffers (xGMI peer mappings); world == 1: this device only
     const uint64_t* c1[PG_MAX_RANKS];   // the c1 buffer being READ this launch
-    const uint64_t* c2[PG_MAX_RANKS];
-    const double* laux[PG_MAX_RANKS];   // la_buf bases (row offset added in the kernel)
+    const uint64_t* c2[PG_MAX_RANKS];   // step API only (pgas_step keeps the ancestor cumsum)
+    const double* la[PG_MAX_RANKS];     // la_buf bases (row offsets are added in the kernel)
+    const double* h[PG_MAX_RANKS];      // h_buf bases
+    const double* ln[PG_MAX_RANKS];     // ln_buf bases
     const double* x[PG_MAX_RANKS];      // x_trace bases
     const int32_t* anc[PG_MAX_RANKS];   // anc_trace bases
     int32_t world, nseg_l, Nl;          // ranks, segments per rank, particles per rank
 };
 
 struct ScanBufs {      // per-step scan scratch (device)
-    double* laux;      // (nseg*SEG)
-    uint64_t* c1;      // (nseg*SEG) quantised inclusive cumsum of the resampling weights
-    uint64_t* c2;      // (nseg*SEG) same for the ancestor weights
-    double* segm;      // segment maxima as READ by the cross-segment scan: (ranks, 2, nsegp) after the all-gather
+    double* laux;      // (nseg*SEG) step API: log p(y_t | aux_t) of k_front
+    uint64_t* c1;      // (nseg*SEG) quantised inclusive cumsum of the resampling weights, per segment
+    uint64_t* c2;      // (nseg*SEG) same for the ancestor weights (step API only)
+    double* segk;      // segment references kref as READ by the group scans: (ranks, 2, nsegp) after the all-gather
     uint64_t* segs;    // segment totals, same layout
-    double* segm_w;    // (2, nsegp) where this device's segment scans WRITE (== segm on a single device)
+    double* segk_w;    // (2, nsegp) where this device's segment scans WRITE (== segk on a single device)
     uint64_t* segs_w;
-    int32_t nseg_l;    // segments per rank in segm/segs (single device: >= nseg, so every segment maps to "rank" 0)
-    int32_t rank_stride;  // words between two ranks' blocks in segm/segs (2 * nsegp_local)
-    double* excl;      // (2, nsegp)
-    double* scale;     // (2, nsegp)
-    double* cm;        // (2, nsegp) running max of the segment-end CDF numerators
+    int32_t nseg_l;    // segments per rank in segk/segs (single device: >= nseg, so every segment maps to "rank" 0)
+    int32_t rank_stride;  // words between two ranks' blocks in segk/segs (2 * nsegp)
+    int32_t nsegp;     // padded LOCAL nseg (multiple of 64): stride between the two CDFs in segk/segs
+    int32_t nsegp_g;   // padded GLOBAL nseg: stride between the two CDFs in tab_*
+    double* tab_e;     // (2, nsegp_g) per-segment records written by k_groups: exclusive prefix inside the group,
+    double* tab_sc;    //              scale 2^(kref - KG),
+    double* tab_m;     //              running maximum of the segment-end values inside the group
+    double* grp_K;     // (2, PG_MAX_GRP) group references KG
+    double* grp_T;     // (2, PG_MAX_GRP) group totals TG
     UpperHdr* hdr;
-    int32_t nsegp;     // padded LOCAL nseg (multiple of 64): stride between the two CDFs in segm/segs
-    int32_t nsegp_g;   // padded global nseg: stride between the two CDFs in excl/scale/cm
 };
 
 // ------------------------------------------------------------------------------------------
@@ -707,602 +709,7 @@ __global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, TransParams tp, i
         lwp[r] = (logw_prev != nullptr && pi < md.N) ? logw_prev[pi] : 0.0;
     }
     front_particles<NX, D, JIN, P>(md, tp, t, seed, ref_t, seg, xv, lwp, corrected, x_new, sb.laux, lw);
-    segment_scan<2>(sm, lw, seg, sb.nsegp, sb.c1, sb.c2, sb.segm_w, sb.segs_w);
-}
-
-// ------------------------------------------------------------------------------------------
-// k_upper: cross-segment CDF.  Block w (0: resampling weights, 1: ancestor weights) turns the
-// segment (max, total) pairs into exclusive prefixes in the canonical KS64-tree order, the
-// running maximum of the segment-end numerators and the normaliser S; block `search_block`
-// additionally counts #{k : W_k < u S} (ancestor of the reference particle, src/PGAS.py:121-124;
-// or the final index, :225).
-//
-// Latency is what matters here (one small workgroup per CDF on the sweep's critical path), so
-// the kernel is organised around few workgroup barriers: wave v owns the level-0 groups
-// g = v, v + 4, ... (64 consecutive segments each, Kogge-Stone by shuffles), the level-1/2 scans
-// are tiny and recomputed by every wave from LDS, and the running maximum needs one more barrier.
-// ------------------------------------------------------------------------------------------
-#define PG_UPPER_WAVES (PG_UPPER_THREADS / 64)
-#define PG_MAX_GROUPS (PG_MAX_NSEG / 64)
-template <int MG>  // capacity in level-0 groups
-struct UpperSmemT {
-    double ga[2][MG];                // level-0 group totals (up to two CDFs scanned together)
-    double gmax[2][MG];              // per-group maximum of the segment-end numerators
-    double red[2][PG_UPPER_WAVES];
-    double par[3];                   // (excl, scale, carry) of one segment, broadcast for cdf_count_block
-    int cnt[2];
-    unsigned long long wsum[PG_UPPER_WAVES];  // wave totals of cdf_count_block_recompute's integer scan
-};
-typedef UpperSmemT<PG_MAX_GROUPS> UpperSmem;
-
-// Cross-segment scan of NC (1 or 2) CDFs by a 256-thread workgroup, sharing the three workgroup barriers.
-// Thread (wave v, lane l) owns segments b = ((v + 4 e) << 6) + l, e < GPW, and gets their exclusive prefix, scale
-// and running maximum in registers; S[c] is the normaliser of CDF c.  CDF c reads segm/segs + c * stride.
-template <int GPW, int NC, class SM>  // level-0 groups (of 64 segments) per wave: nseg <= 64 * PG_UPPER_WAVES * GPW
-__device__ __forceinline__ void upper_core(SM& sm, const double* __restrict__ segm, const uint64_t* __restrict__ segs, int stride,
-                                           int nseg, double (&excl)[NC][GPW], double (&scale)[NC][GPW], double (&cmx)[NC][GPW],
-                                           double (&S)[NC], int nseg_l = 0x40000000, int rank_stride = 0) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n1 = (nseg + 63) >> 6;  // level-0 groups
-    const int n2 = (n1 + 63) >> 6;    // <= 2 for nseg <= 8192
-
-    // 1. global max of the segment maxima (group g of wave v: g = v + PG_UPPER_WAVES * e)
-    double mv[NC][GPW];
-    uint64_t sv[NC][GPW];
-    double g[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        g[c] = -__builtin_inf();
-#pragma unroll
-        for (int e = 0; e < GPW; ++e) {
-            const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
-            mv[c][e] = -__builtin_inf();
-            sv[c][e] = 0;
-            if (b < nseg) {
-                const size_t at = (size_t)c * stride + (size_t)(b / nseg_l) * rank_stride + (b % nseg_l);  // (rank, cdf, local segment)
-                mv[c][e] = segm[at];
-                sv[c][e] = segs[at];
-            }
-            g[c] = __builtin_fmax(g[c], mv[c][e]);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        g[c] = wave_max(g[c]);
-        if (lane == 0) sm.red[c][wave] = g[c];
-    }
-    if (tid < 2) sm.cnt[tid] = 0;
-    PG_STAMP(8);
-    __syncthreads();
-    PG_STAMP(9);
-    // 2. scaled totals and level-0 Kogge-Stone scans
-    double tot[NC][GPW], incA[NC][GPW];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        g[c] = sm.red[c][0];
-#pragma unroll
-        for (int v = 1; v < PG_UPPER_WAVES; ++v) g[c] = __builtin_fmax(g[c], sm.red[c][v]);
-        double ev[GPW];
-#pragma unroll
-        for (int e = 0; e < GPW; ++e) ev[e] = pgas_seg_scale(mv[c][e], g[c]);  // exact power of two: no exp across segments
-#pragma unroll
-        for (int e = 0; e < GPW; ++e) {
-            const int gi = wave + PG_UPPER_WAVES * e;
-            const int b = (gi << 6) + lane;
-            tot[c][e] = 0.0;
-            incA[c][e] = 0.0;
-            scale[c][e] = 0.0;
-            if (gi < n1) {  // wave-uniform
-                double sc = ev[e];
-                if (!(sc >= 0.0)) sc = 0.0;
-                if (b < nseg) {
-                    scale[c][e] = sc;
-                    tot[c][e] = sc * (pgas_u64_to_double(sv[c][e]) * PGAS_FIX_INV);
-                }
-                incA[c][e] = wave_scan_add(tot[c][e]);
-                if (lane == 63) sm.ga[c][gi] = incA[c][e];
-            }
-        }
-    }
-    PG_STAMP(10);
-    __syncthreads();
-    PG_STAMP(11);
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        // 3. levels 1 and 2, recomputed by every wave: incB over the group totals (groups of 64), incC over those
-        double incB0 = wave_scan_add(lane < n1 ? sm.ga[c][lane] : 0.0);                            // level-1 group 0
-        double incB1 = n2 > 1 ? wave_scan_add(64 + lane < n1 ? sm.ga[c][64 + lane] : 0.0) : 0.0;   // level-1 group 1
-        const double GB0 = readlane_f64(incB0, 63);  // level 2 (zero padded): incC[0] = GB0
-        // 4. exclusive prefixes, segment-end numerators, per-group running maxima
-#pragma unroll
-        for (int e = 0; e < GPW; ++e) {
-            const int gi = wave + PG_UPPER_WAVES * e;
-            const int b = (gi << 6) + lane;
-            const int h = gi >> 6, l1 = gi & 63;
-            const double eC = h ? GB0 : 0.0;
-            const double srcB = h ? incB1 : incB0;
-            const double prevB = readlane_f64(srcB, l1 ? l1 - 1 : 0);
-            const double eB = l1 ? prevB : 0.0;
-            const double exB = eC + eB;
-            double wend = 0.0;
-            cmx[c][e] = 0.0;
-            excl[c][e] = 0.0;
-            if (gi < n1) {
-                const double up = __shfl_up(incA[c][e], 1);
-                const double eA = lane ? up : 0.0;
-                const double ex = exB + eA;
-                if (b < nseg) {
-                    excl[c][e] = ex;
-                    wend = ex + tot[c][e];
-                }
-                cmx[c][e] = wave_scan_max(wend);
-                if (lane == 63) sm.gmax[c][gi] = cmx[c][e];
-            }
-        }
-    }
-    PG_STAMP(12);
-    __syncthreads();
-    PG_STAMP(13);
-    // 5. running maximum across groups (exact, any order): carry of group gi = max of gmax[0..gi)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-        double m0 = wave_scan_max(lane < n1 ? sm.gmax[c][lane] : 0.0);
-        double m1 = n2 > 1 ? wave_scan_max(64 + lane < n1 ? sm.gmax[c][64 + lane] : 0.0) : 0.0;
-        const double M0 = readlane_f64(m0, 63), M1 = readlane_f64(m1, 63);
-#pragma unroll
-        for (int e = 0; e < GPW; ++e) {
-            const int gi = wave + PG_UPPER_WAVES * e;
-            if (gi < n1) {
-                const int h = gi >> 6, l1 = gi & 63;
-                const double src = h ? m1 : m0;
-                const double prev = readlane_f64(src, l1 ? l1 - 1 : 0);
-                double carry = l1 ? prev : 0.0;
-                if (h) carry = __builtin_fmax(carry, M0);
-                cmx[c][e] = __builtin_fmax(cmx[c][e], carry);
-            }
-        }
-        S[c] = __builtin_fmax(M0, M1);
-    }
-}
-
-// #{k : W_k < tau} for one CDF whose cross-segment scan sits in registers -- the searchsorted of
-// src/PGAS.py:122-124 / :225.  Three workgroup barriers; sm.cnt must be zero on entry (upper_core leaves it so).
-template <int GPW, class SM>
-__device__ __forceinline__ int cdf_count_block(SM& sm, const double (&ex)[GPW], const double (&sc)[GPW], const double (&cmx)[GPW],
-                                               int nseg, int N, double tau, const uint64_t* __restrict__ cbuf_local,
-                                               const uint64_t* const* cbuf_ranks = nullptr, int nseg_l = 0x40000000) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int c = 0;
-#pragma unroll
-    for (int e = 0; e < GPW; ++e) {
-        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
-        c += (b < nseg && cmx[e] < tau) ? 1 : 0;
-    }
-    c = wave_sum_i(c);
-    if (lane == 0 && c) atomicAdd(&sm.cnt[0], c);
-    if (tid == 0) sm.par[2] = 0.0;
-    __syncthreads();
-    const int bs = sm.cnt[0];
-    if (bs >= nseg) return N - 1;
-#pragma unroll
-    for (int e = 0; e < GPW; ++e) {  // the owners of segments bs and bs-1 publish (excl, scale) and the carry
-        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
-        if (b == bs) {
-            sm.par[0] = ex[e];
-            sm.par[1] = sc[e];
-        }
-        if (b == bs - 1) sm.par[2] = cmx[e];
-    }
-    __syncthreads();
-    const int64_t base = (int64_t)bs * PGAS_SEG;
-    const int n = (N - base) < PGAS_SEG ? (int)(N - base) : PGAS_SEG;
-    const double e0 = sm.par[0], s0 = sm.par[1], cy = sm.par[2];
-    const uint64_t* __restrict__ cseg = cbuf_ranks ? cbuf_ranks[bs / nseg_l] + (size_t)(bs % nseg_l) * PGAS_SEG : cbuf_local + base;
-    int k = 0;
-    for (int i = tid; i < n; i += PG_UPPER_THREADS) {
-        double num = e0 + s0 * (pgas_u64_to_double(cseg[i]) * PGAS_FIX_INV);
-        num = __builtin_fmax(num, cy);
-        k += (num < tau) ? 1 : 0;
-    }
-    k = wave_sum_i(k);
-    if (lane == 0 && k) atomicAdd(&sm.cnt[1], k);
-    __syncthreads();
-    const int64_t r = base + sm.cnt[1];
-    return r > N - 1 ? N - 1 : (int)r;
-}
-
-// The ancestor CDF of a step (src/PGAS.py:117-124) is read in ONE segment only: the one the reference particle's uniform falls
-// into.  k_resample_fast therefore never stores its per-particle cumsum; the workgroup that draws the ancestor rebuilds that
-// segment from what the sweep already keeps in HBM -- lw2_i = (la_s[i] + logw_{s-1}[i]) + h_s[i] with
-// logw_{s-1}[i] = ln_{s-1}[i] - la_{s-1}[a_{s-1}[i]] (0 for s = 1), the same expressions, the segment's stored reference k,
-// the same fixed-point numerators and an exact integer cumsum -- and counts against it.  Bit-identical to the stored version.
-struct AncInputs {
-    const double* la_s;       // (np) log p(y_s | aux_s)
-    const double* h_s;        // (np) log N(ref_s; aux_s, S)
-    const double* ln_p;       // (np) log p(y_{s-1} | x_{s-1}), or nullptr for s = 1
-    const double* la_p;       // (np) log p(y_{s-1} | aux_{s-1})
-    const int32_t* anc_p;     // (N)  ancestors of step s-1
-    const double* kref;       // (nseg) segment references of the ancestor CDF of step s
-};
-template <int GPW, class SM>
-__device__ __forceinline__ int cdf_count_block_recompute(SM& sm, const double (&ex)[GPW], const double (&sc)[GPW], const double (&cmx)[GPW],
-                                                         int nseg, int N, double tau, const AncInputs& in) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int c = 0;
-#pragma unroll
-    for (int e = 0; e < GPW; ++e) {
-        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
-        c += (b < nseg && cmx[e] < tau) ? 1 : 0;
-    }
-    c = wave_sum_i(c);
-    if (lane == 0 && c) atomicAdd(&sm.cnt[0], c);
-    if (tid == 0) sm.par[2] = 0.0;
-    __syncthreads();
-    const int bs = sm.cnt[0];
-    if (bs >= nseg) return N - 1;
-#pragma unroll
-    for (int e = 0; e < GPW; ++e) {
-        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
-        if (b == bs) {
-            sm.par[0] = ex[e];
-            sm.par[1] = sc[e];
-        }
-        if (b == bs - 1) sm.par[2] = cmx[e];
-    }
-    const int64_t base = (int64_t)bs * PGAS_SEG;
-    const int n = (N - base) < PGAS_SEG ? (int)(N - base) : PGAS_SEG;
-    const double kref = in.kref[bs];
-    double arg[PG_PPT], ev[PG_PPT];
-#pragma unroll
-    for (int j = 0; j < PG_PPT; ++j) {
-        const int i = PG_PPT * tid + j;
-        double lw2 = -__builtin_inf();
-        if (i < n) {
-            const int64_t gi = base + i;
-            double logw = 0.0;
-            if (in.ln_p) logw = in.ln_p[gi] - in.la_p[in.anc_p[gi]];
-            const double l1 = in.la_s[gi] + logw;
-            lw2 = l1 + in.h_s[gi];
-        }
-        arg[j] = pgas_seg_arg(lw2, kref);
-    }
-    pgas_exp_n(arg, ev, PG_PPT);
-    uint64_t loc[PG_PPT], run = 0;
-#pragma unroll
-    for (int j = 0; j < PG_PPT; ++j) {
-        run += (ev[j] > 0.0) ? pgas_double_to_u64(__builtin_rint(ev[j] * PGAS_FIX_SCALE)) : 0ull;
-        loc[j] = run;
-    }
-    const uint64_t incl = wave_incl_scan_u64(run);
-    if (lane == 63) sm.wsum[wave] = incl;
-    __syncthreads();
-    uint64_t off = incl - run;
-#pragma unroll
-    for (int v = 0; v < PG_UPPER_WAVES; ++v)
-        if (v < wave) off += sm.wsum[v];
-    const double e0 = sm.par[0], s0 = sm.par[1], cy = sm.par[2];
-    int k = 0;
-#pragma unroll
-    for (int j = 0; j < PG_PPT; ++j) {
-        double num = e0 + s0 * (pgas_u64_to_double(off + loc[j]) * PGAS_FIX_INV);
-        num = __builtin_fmax(num, cy);
-        k += (PG_PPT * tid + j < n && num < tau) ? 1 : 0;
-    }
-    k = wave_sum_i(k);
-    if (lane == 0 && k) atomicAdd(&sm.cnt[1], k);
-    __syncthreads();
-    const int64_t r = base + sm.cnt[1];
-    return r > N - 1 ? N - 1 : (int)r;
-}
-
-template <int GPW>
-__global__ __launch_bounds__(PG_UPPER_THREADS) void k_upper(int N, int nseg, ScanBufs sb, Peers pr, int search_block, double u_search,
-                                                             int final_mode) {
-    // N, nseg: GLOBAL particle / segment counts (every rank of a sharded sweep runs this kernel on the gathered partials
-    // and gets identical results)
-    __shared__ UpperSmem sm;
-    const int w = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    double* __restrict__ excl = sb.excl + (size_t)w * sb.nsegp_g;
-    double* __restrict__ scale = sb.scale + (size_t)w * sb.nsegp_g;
-    double* __restrict__ cm = sb.cm + (size_t)w * sb.nsegp_g;
-    double ex[1][GPW], sc[1][GPW], cmx[1][GPW], Sv[1];
-    upper_core<GPW, 1>(sm, sb.segm + (size_t)w * sb.nsegp, sb.segs + (size_t)w * sb.nsegp, 0, nseg, ex, sc, cmx, Sv, sb.nseg_l, sb.rank_stride);
-    const double S = Sv[0];
-#pragma unroll
-    for (int e = 0; e < GPW; ++e) {
-        const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
-        if (b < nseg) {
-            excl[b] = ex[0][e];
-            scale[b] = sc[0][e];
-            cm[b] = cmx[0][e];
-        }
-    }
-    const bool valid = (S > 0.0) && (S < __builtin_inf());
-    if (tid == 0) {
-        sb.hdr->S[w] = S;
-        sb.hdr->valid[w] = valid ? 1 : 0;
-    }
-    if (w != search_block) return;
-    int result = N - 1;
-    if (valid)
-        result = cdf_count_block<GPW>(sm, ex[0], sc[0], cmx[0], nseg, N, u_search * S, w == 0 ? sb.c1 : sb.c2,
-                                      pr.world > 1 ? (w == 0 ? pr.c1 : pr.c2) : nullptr, pr.nseg_l);
-    if (tid == 0) {
-        if (final_mode)
-            sb.hdr->final_idx = result;
-        else
-            sb.hdr->ref_idx = result;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// back half: systematic resampling search (src/Filtering.py:28-35) + weight update
-// (src/PGAS.py:137-147).
-//
-// Slot i = seg*SEG + 4*tid + j (four CONSECUTIVE slots per thread for the search; the thresholds
-// tau_i = U_i * S grow with i).  The workgroup finds the range of source segments its slots fall
-// into (two counts over the running-max array cm), stages the CDF numerators of up to
-// PG_STAGE segments at a time in LDS as doubles -- num_k = max(carry, excl + scale * c_k 2^-51),
-// evaluated once per source -- and every slot does a lower-bound search with plain double
-// compares.  Ancestors then go through LDS to the particle-major (strided) layout the front
-// half uses.
-// ------------------------------------------------------------------------------------------
-#define PG_STAGE 3
-struct BackSmem {
-    double num[PG_STAGE][PGAS_SEG];
-    int a[PGAS_SEG];
-    int red[2][PG_BLK / 64];
-};
-
-// Resampling slot j of thread tid inside its workgroup's 1024 slots: lanes of a wave take consecutive slots (for every j),
-// so that the lower-bound probes of a wave fall on consecutive LDS words (no bank conflicts).
-__device__ __forceinline__ int slot_of(int tid, int j) { return ((tid >> 6) << 8) + (j << 6) + (tid & 63); }
-
-__device__ __forceinline__ double slot_tau(double u1, int64_t i, int N, double invN, bool pow2, double S) {
-    const double x = u1 + (double)i;
-    const double Ui = pow2 ? x * invN : x / (double)N;  // exact either way when N is a power of two
-    return Ui * S;
-}
-
-// c1 data of GLOBAL source segment bs (this device's buffer, or a peer's through its xGMI mapping)
-__device__ __forceinline__ const uint64_t* c1_segment(const ScanBufs& sb, const Peers& pr, int bs) {
-    return pr.world > 1 ? pr.c1[bs / pr.nseg_l] + (size_t)(bs % pr.nseg_l) * PGAS_SEG : sb.c1 + (size_t)bs * PGAS_SEG;
-}
-
-// Search for the 1024 slots of local segment `seg`.  All indices that leave this function are GLOBAL particle indices;
-// md.p0 / md.Ng / md.nseg_g place the device's shard in the global particle range (single device: 0 / N / nseg).
-__device__ __forceinline__ void resample_slots(const DevModel& md, BackSmem& sm, double u1, const ScanBufs& sb, const Peers& pr, int seg,
-                                               int32_t* __restrict__ anc_out, int (&anc_pm)[PG_PPT], bool conditioned = true) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nseg = md.nseg_g, N = md.Ng;
-    const double S = sb.hdr->S[0];
-    const bool valid = sb.hdr->valid[0] != 0;
-    const bool pow2 = (N & (N - 1)) == 0;
-    const double invN = 1.0 / (double)N;
-    const double* __restrict__ cm = sb.cm;
-    const int64_t loc_i = (int64_t)seg * PGAS_SEG;    // local index of slot 0 of this workgroup
-    const int64_t base_i = md.p0 + loc_i;             // its global index
-    const int nslots = (md.N - loc_i) < PGAS_SEG ? (int)(md.N - loc_i) : PGAS_SEG;
-
-    double tau[PG_PPT];
-    int a[PG_PPT];
-#pragma unroll
-    for (int j = 0; j < PG_PPT; ++j) {
-        const int64_t i = base_i + slot_of(tid, j);
-        tau[j] = slot_tau(u1, i, N, invN, pow2, S);
-        a[j] = valid ? N - 1 : (int)(i < N ? i : N - 1);
-    }
-    if (valid) {  // uniform
-        // source-segment range of this workgroup: b_lo = #{b: cm[b] < tau_first}, b_hi = #{b: cm[b] < tau_last}
-        const double tau_first = slot_tau(u1, base_i, N, invN, pow2, S);
-        const double tau_last = slot_tau(u1, base_i + nslots - 1, N, invN, pow2, S);
-        int clo = 0, chi = 0;
-        for (int b = tid; b < nseg; b += PG_BLK) {
-            const double v = cm[b];
-            clo += (v < tau_first) ? 1 : 0;
-            chi += (v < tau_last) ? 1 : 0;
-        }
-        clo = wave_sum_i(clo);
-        chi = wave_sum_i(chi);
-        if (lane == 0) {
-            sm.red[0][wave] = clo;
-            sm.red[1][wave] = chi;
-        }
-        __syncthreads();
-        int b_lo = 0, b_hi = 0;
-#pragma unroll
-        for (int v = 0; v < PG_BLK / 64; ++v) {
-            b_lo += sm.red[0][v];
-            b_hi += sm.red[1][v];
-        }
-        if (b_hi > nseg - 1) b_hi = nseg - 1;  // slots beyond the last segment keep a = N-1
-        // non-empty segments of [b_lo, b_hi] (running max moved), found by bisection jumps over cm: the next one after
-        // carry c is #{b : cm[b] <= c}.  Bounded work however long the run of empty segments is.
-        int sb_idx[PG_STAGE];
-        double g_carry = 0.0;
-        int ns = 0, b = b_lo;
-        while (ns <= PG_STAGE) {
-            const double c0 = b ? cm[b - 1] : 0.0;
-            int lo = b, hi = nseg;  // first index >= b with cm > c0
-            while (lo < hi) {
-                const int mid = (lo + hi) >> 1;
-                if (cm[mid] <= c0) lo = mid + 1; else hi = mid;
-            }
-            if (lo > b_hi) break;
-            if (ns == 0) g_carry = c0;
-            if (ns < PG_STAGE) sb_idx[ns] = lo;
-            ++ns;
-            b = lo + 1;
-        }
-        if (ns > 0 && ns <= PG_STAGE) {
-            // ---- common case: the workgroup's slots fall into at most PG_STAGE source segments.  Stage their
-            // numerators back to back; they are non-decreasing across the whole window (running-max carry),
-            // so one branch-free lower-bound search per slot settles every slot.
-#pragma unroll
-            for (int g = 0; g < PG_STAGE; ++g) {
-                double4 v = make_double4(__builtin_inf(), __builtin_inf(), __builtin_inf(), __builtin_inf());
-                if (g < ns) {
-                    const int bs = sb_idx[g];
-                    const double ex = sb.excl[bs], sc = sb.scale[bs], cy = bs ? cm[bs - 1] : 0.0;
-                    const int64_t base_k = (int64_t)bs * PGAS_SEG;
-                    const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
-                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(c1_segment(sb, pr, bs)) + 2 * tid;
-                    const ulonglong2 c01 = src[0], c23 = src[1];
-                    const int k0 = PG_PPT * tid;
-                    if (k0 + 0 < n) v.x = __builtin_fmax(ex + sc * (pgas_u64_to_double(c01.x) * PGAS_FIX_INV), cy);
-                    if (k0 + 1 < n) v.y = __builtin_fmax(ex + sc * (pgas_u64_to_double(c01.y) * PGAS_FIX_INV), cy);
-                    if (k0 + 2 < n) v.z = __builtin_fmax(ex + sc * (pgas_u64_to_double(c23.x) * PGAS_FIX_INV), cy);
-                    if (k0 + 3 < n) v.w = __builtin_fmax(ex + sc * (pgas_u64_to_double(c23.y) * PGAS_FIX_INV), cy);
-                }
-                reinterpret_cast<double4*>(sm.num[g])[tid] = v;
-            }
-            __syncthreads();
-            const double* __restrict__ num = &sm.num[0][0];
-            int pos[PG_PPT] = {0, 0, 0, 0};
-#pragma unroll
-            for (int step = 2048; step >= 1; step >>= 1) {
-#pragma unroll
-                for (int j = 0; j < PG_PPT; ++j) {  // loads are unconditional so the four chains advance in lock step
-                    const int q = pos[j] + step;
-                    const int qc = q <= PG_STAGE * PGAS_SEG ? q : PG_STAGE * PGAS_SEG;
-                    const double v = num[qc - 1];
-                    pos[j] = (q <= PG_STAGE * PGAS_SEG && v < tau[j]) ? q : pos[j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < PG_PPT; ++j) {
-                if (g_carry < tau[j] && pos[j] < ns * PGAS_SEG) {
-                    const int g = pos[j] >> 10, off = pos[j] & (PGAS_SEG - 1);
-                    const int64_t ai = (int64_t)(g == 0 ? sb_idx[0] : g == 1 ? sb_idx[1] : sb_idx[2]) * PGAS_SEG + off;
-                    a[j] = ai > N - 1 ? N - 1 : (int)ai;
-                }
-            }
-        } else if (ns > PG_STAGE) {
-            // ---- degenerate weights: the slots of this workgroup spread over many source segments.  Staging them
-            // all would make this workgroup the straggler of the launch, so every slot searches for itself:
-            // segment by bisection over cm (global, cache resident), then bisection inside the segment.
-            int sbi[PG_PPT];
-#pragma unroll
-            for (int j = 0; j < PG_PPT; ++j) {
-                int lo = b_lo, hi = b_hi + 1;  // b_i = #{b : cm[b] < tau}
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (cm[mid] < tau[j]) lo = mid + 1; else hi = mid;
-                }
-                sbi[j] = lo;
-            }
-#pragma unroll
-            for (int j = 0; j < PG_PPT; ++j) {
-                const int bs = sbi[j];
-                if (bs < nseg) {
-                    const double ex = sb.excl[bs], sc = sb.scale[bs], cy = bs ? cm[bs - 1] : 0.0;
-                    const int64_t base_k = (int64_t)bs * PGAS_SEG;
-                    const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
-                    const uint64_t* __restrict__ c = c1_segment(sb, pr, bs);
-                    int lo = 0, hi = n;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        const double v = __builtin_fmax(ex + sc * (pgas_u64_to_double(c[mid]) * PGAS_FIX_INV), cy);
-                        if (v < tau[j]) lo = mid + 1; else hi = mid;
-                    }
-                    const int64_t ai = base_k + lo;
-                    a[j] = ai > N - 1 ? N - 1 : (int)ai;
-                }
-            }
-        }
-    }
-    // slot-major -> particle-major through LDS; the conditioned particle takes the ancestor drawn by k_upper
-#pragma unroll
-    for (int j = 0; j < PG_PPT; ++j) {
-        const int64_t i = base_i + slot_of(tid, j);
-        if (conditioned && i == N - 1) a[j] = sb.hdr->ref_idx;  // src/PGAS.py:127
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < PG_PPT; ++j) {
-        sm.a[slot_of(tid, j)] = a[j];
-        if (loc_i + slot_of(tid, j) < md.N) anc_out[loc_i + slot_of(tid, j)] = a[j];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) anc_pm[r] = sm.a[r * PG_BLK + tid];  // ancestor of local particle loc_i + r*BLK + tid
-}
-
-template <int NX>
-__device__ __forceinline__ void back_slots(const DevModel& md, BackSmem& sm, int t, double u1, const ScanBufs& sb, int seg,
-                                           const double (&xcur)[PG_PPT][NX], int32_t* __restrict__ anc_out, double (&logw_new)[PG_PPT]) {
-    const int tid = threadIdx.x;
-    int anc[PG_PPT];
-    Peers none;
-    none.world = 1;
-    resample_slots(md, sm, u1, sb, none, seg, anc_out, anc);
-    const double* __restrict__ yt = md.y + (size_t)t * md.ny;
-#pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) {
-        const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-        logw_new[r] = 0.0;
-        if (i < md.N) logw_new[r] = loglik<NX>(md, yt, xcur[r]) - sb.laux[anc[r]];
-    }
-}
-
-template <int NX>
-__global__ __launch_bounds__(PG_BLK) void k_back(DevModel md, int t, double u1, const double* __restrict__ x_cur, ScanBufs sb,
-                                                  int32_t* __restrict__ anc_out, double* __restrict__ logw_out) {
-    __shared__ BackSmem sm;
-    const int seg = blockIdx.x, tid = threadIdx.x;
-    double xv[PG_PPT][NX], lwn[PG_PPT];
-    load_particles<NX>(md, x_cur, seg, xv);
-    back_slots<NX>(md, sm, t, u1, sb, seg, xv, anc_out, lwn);
-#pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) {
-        const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-        if (i < md.N) logw_out[i] = lwn[r];
-    }
-}
-
-// k_back_corrected: the second half of a step in the CORRECTED mode (resample_before_propagate; quirk Q1 removed):
-//   a = systematic resampling search,  x_new_i = aux[a_i] + L_S z_i  (conditioned particle = ref_t),
-//   logw_new_i = log p(y_t | x_new_i) - l_aux[a_i].
-// aux holds the transition means k_front stored; the noise z_i is the same Philox draw the default mode uses for
-// particle i at time t, so the two modes differ only in which mean the noise is added to.
-template <int NX>
-__global__ __launch_bounds__(PG_BLK) void k_back_corrected(DevModel md, TransParams tp, int t, uint64_t seed, double u1,
-                                                            const double* __restrict__ aux, const double* __restrict__ ref_t, ScanBufs sb,
-                                                            int32_t* __restrict__ anc_out, double* __restrict__ x_new,
-                                                            double* __restrict__ logw_out) {
-    __shared__ BackSmem sm;
-    const int seg = blockIdx.x, tid = threadIdx.x;
-    int anc[PG_PPT];
-    Peers none;
-    none.world = 1;
-    resample_slots(md, sm, u1, sb, none, seg, anc_out, anc);
-    const double* __restrict__ yt = md.y + (size_t)t * md.ny;
-    double z0[PG_PPT], z1[PG_PPT];
-    {
-        pgas_u32x4 w[PG_PPT];
-#pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
-            const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-            w[r] = pgas_rng_block(seed, PGAS_STREAM_PROP, 0u, (uint32_t)t, (uint64_t)(md.p0 + pi));
-        }
-        pgas_normal_pair_n(w, z0, z1, PG_PPT);
-    }
-    double xn[PG_PPT][NX];
-#pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) {
-        const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-        const int src = pi < md.N ? anc[r] : 0;
-        const double z[2] = {z0[r], z1[r]};
-#pragma unroll
-        for (int k = 0; k < NX; ++k) {
-            double v = aux[(size_t)src * NX + k];
-#pragma unroll
-            for (int l = 0; l <= k; ++l) v = PGAS_FMA(tp.LS[k * NX + l], z[l], v);
-            xn[r][k] = (md.p0 + pi == md.Ng - 1) ? ref_t[k] : v;
-        }
-        if (pi < md.N) logw_out[pi] = loglik<NX>(md, yt, xn[r]) - sb.laux[src];
-    }
-    store_particles<NX>(md, x_new, seg, xn);
+    segment_scan<2>(sm, lw, seg, sb.nsegp, sb.c1, sb.c2, sb.segk_w, sb.segs_w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1342,352 +749,6 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
     }
 }
 
-// mode bits of k_resample
-#define PG_RS_SEARCH 1  // resample step t-1 (sb_prev valid) and form logw_{t-1}; otherwise logw_{t-1} = 0 (t = 1)
-#define PG_RS_SCAN 2    // scan step t's weights into sb_next; otherwise only emit logw_{t-1} (after the last step)
-__global__ __launch_bounds__(PG_BLK) void k_resample(DevModel md, int t, int mode, double u1_prev, const double* __restrict__ la_t,
-                                                      const double* __restrict__ h_t, const double* __restrict__ ln_prev,
-                                                      ScanBufs sb_prev, ScanBufs sb_next, Peers pr, int64_t laux_row_off,
-                                                      int32_t* __restrict__ anc_out, double* __restrict__ logw_out) {
-    __shared__ union {
-        BackSmem b;
-        ScanSmem s;
-    } sm;
-    const int seg = blockIdx.x, tid = threadIdx.x;
-    double lwp[PG_PPT] = {0.0, 0.0, 0.0, 0.0};
-    if (mode & PG_RS_SEARCH) {
-        double lnv[PG_PPT];
-#pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) lnv[r] = ln_prev[(size_t)seg * PGAS_SEG + r * PG_BLK + tid];
-        int anc[PG_PPT];
-        resample_slots(md, sm.b, u1_prev, sb_prev, pr, seg, anc_out, anc);
-#pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
-            const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-            if (i < md.N) {
-                // log p(y_{t-1} | aux_{t-1}) of the ancestor: this device's row, or the owning peer's (src/PGAS.py:146)
-                const double la_anc = pr.world > 1 ? pr.laux[anc[r] / pr.Nl][laux_row_off + anc[r] % pr.Nl] : sb_prev.laux[anc[r]];
-                lwp[r] = lnv[r] - la_anc;
-            }
-        }
-        if (logw_out != nullptr) {
-#pragma unroll
-            for (int r = 0; r < PG_PPT; ++r) {
-                const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
-                if (i < md.N) logw_out[i] = lwp[r];
-            }
-        }
-        __syncthreads();  // BackSmem -> ScanSmem reuse
-    }
-    if (mode & PG_RS_SCAN) {
-        double lw[2][PG_PPT];
-#pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
-            const size_t pi = (size_t)seg * PGAS_SEG + r * PG_BLK + tid;
-            const bool valid = pi < (size_t)md.N;
-            const double l1 = la_t[pi] + lwp[r];
-            lw[0][r] = valid ? l1 : -__builtin_inf();
-            lw[1][r] = valid ? l1 + h_t[pi] : -__builtin_inf();
-        }
-        segment_scan<2>(sm.s, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm_w, sb_next.segs_w);
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_resample_fast: k_resample with the cross-segment scan of step t-1 folded in (no k_upper launch on
-// the critical path).  Every workgroup recomputes the scan of the resampling CDF from the nseg <= 1024
-// segment (max,total) pairs -- 16 KB from L2, three barriers -- keeps its running maximum in LDS, and goes
-// straight on to the search.  The workgroup that owns the conditioned particle N-1 also scans the
-// ancestor CDF and draws the reference particle's ancestor (src/PGAS.py:121-127).  Bit-identical to the
-// k_upper + k_resample pair (same upper_core, same search).
-// ------------------------------------------------------------------------------------------
-#define PG_FAST_GPW 4
-#define PG_FGROUPS 4  // at most this many staged windows per workgroup before falling back to per-slot bisection
-#define PG_FSTAGE 2   // source segments staged at once by k_resample_fast (LDS budget: five workgroups per CU)
-#define PG_FAST_NSEG (64 * PG_UPPER_WAVES * PG_FAST_GPW)
-struct FastSmem {
-    double cm[PG_FAST_NSEG];
-    union {
-        double num[PG_FSTAGE][PGAS_SEG];
-        struct {
-            double excl[PG_FAST_NSEG], scale[PG_FAST_NSEG];
-        } tab;
-        ScanSmem scan;
-        int a[PGAS_SEG];  // ancestors, slot-major -> particle-major exchange (after the search is done with `num`)
-    } u;
-    // candidate source segments of this workgroup (index, excl, scale, carry): copied out of `tab` before staging reuses it
-    int cand_b[PG_FGROUPS * PG_FSTAGE];
-    double cand_ex[PG_FGROUPS * PG_FSTAGE], cand_sc[PG_FGROUPS * PG_FSTAGE], cand_cy[PG_FGROUPS * PG_FSTAGE];
-    UpperSmemT<PG_UPPER_WAVES * PG_FAST_GPW> up;
-};
-
-// Grid = nseg + 1 workgroups.  Workgroup 0 only draws the reference particle's ancestor (scan of the ancestor CDF + one
-// count, src/PGAS.py:121-127) and publishes it as one 8-byte {launch tag, index} word; workgroup b + 1 owns segment b.
-// The workgroup that owns the conditioned particle reads that word late (after its own search).  Workgroup 0 never
-// waits for anyone, so the hand-off cannot deadlock whatever the dispatch order; if the word has not arrived within the
-// spin budget the owner computes the ancestor itself (same code, same result).
-__global__ __launch_bounds__(PG_BLK, 5) void k_resample_fast(DevModel md, int t, int mode, unsigned tag, double u1_prev, double u2_prev, AncInputs anc_in,
-                                                           const double* __restrict__ la_t, const double* __restrict__ h_t,
-                                                           const double* __restrict__ ln_prev, ScanBufs sb_prev, ScanBufs sb_next,
-                                                           int32_t* __restrict__ anc_out, double* __restrict__ logw_out) {
-    __shared__ FastSmem sm;
-    constexpr int GPW = PG_FAST_GPW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int nseg = md.nseg, N = md.N;
-    if (blockIdx.x == 0) {  // ---- ancestor workgroup
-        if (!(mode & PG_RS_SEARCH)) return;
-        double ex2[1][GPW], sc2[1][GPW], cm2[1][GPW], S2[1];
-        upper_core<GPW, 1>(sm.up, sb_prev.segm + sb_prev.nsegp, sb_prev.segs + sb_prev.nsegp, 0, nseg, ex2, sc2, cm2, S2);
-        int r = N - 1;
-        if ((S2[0] > 0.0) && (S2[0] < __builtin_inf()))
-            r = cdf_count_block_recompute<GPW>(sm.up, ex2[0], sc2[0], cm2[0], nseg, N, u2_prev * S2[0], anc_in);
-        if (tid == 0)
-            __hip_atomic_store(&sb_prev.hdr->ref_granule, ((unsigned long long)tag << 32) | (unsigned)r, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    const int seg = blockIdx.x - 1;
-    const int64_t base_i = (int64_t)seg * PGAS_SEG;
-    PG_STAMP(0);
-    // own-particle inputs first: their latency overlaps the scan below
-    double lnv[PG_PPT];
-#pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) lnv[r] = (mode & PG_RS_SEARCH) ? ln_prev[(size_t)base_i + r * PG_BLK + tid] : 0.0;
-    double lwp[PG_PPT] = {0.0, 0.0, 0.0, 0.0};
-    if (mode & PG_RS_SEARCH) {
-        const int nsegp = sb_prev.nsegp;
-        // ---- cross-segment scan of the resampling CDF of step t-1; the workgroup that owns the conditioned particle
-        // scans the ancestor CDF in the same pass (shared barriers) and draws the reference particle's ancestor
-        // (src/PGAS.py:121-127)
-        const bool last_wg = base_i + PGAS_SEG >= N;  // uniform
-        double ex[GPW], sc[GPW], cmx[GPW], S;
-        {
-            double ex1[1][GPW], sc1[1][GPW], cm1[1][GPW], S1[1];
-            upper_core<GPW, 1>(sm.up, sb_prev.segm, sb_prev.segs, 0, nseg, ex1, sc1, cm1, S1);
-#pragma unroll
-            for (int e = 0; e < GPW; ++e) {
-                ex[e] = ex1[0][e];
-                sc[e] = sc1[0][e];
-                cmx[e] = cm1[0][e];
-            }
-            S = S1[0];
-        }
-        const bool valid = (S > 0.0) && (S < __builtin_inf());
-        PG_STAMP(1);
-#pragma unroll
-        for (int e = 0; e < GPW; ++e) {
-            const int b = ((wave + PG_UPPER_WAVES * e) << 6) + lane;
-            sm.cm[b] = b < nseg ? cmx[e] : __builtin_inf();
-            sm.u.tab.excl[b] = ex[e];
-            sm.u.tab.scale[b] = sc[e];
-        }
-        __syncthreads();
-        const bool pow2 = (N & (N - 1)) == 0;
-        const double invN = 1.0 / (double)N;
-        const int nslots = (N - base_i) < PGAS_SEG ? (int)(N - base_i) : PGAS_SEG;
-        double tau[PG_PPT];
-        int a[PG_PPT];
-#pragma unroll
-        for (int j = 0; j < PG_PPT; ++j) {
-            const int64_t i = base_i + slot_of(tid, j);
-            tau[j] = slot_tau(u1_prev, i, N, invN, pow2, S);
-            a[j] = valid ? N - 1 : (int)(i < N ? i : N - 1);
-        }
-        int ns = 0;  // non-empty source segments in [b_lo, b_hi], counted up to PG_FGROUPS * PG_FSTAGE + 1
-        int b_lo = 0, b_hi = 0;
-        if (valid) {  // uniform
-            // source-segment range of this workgroup: lower bounds over the running maxima (branch-free bisection, LDS)
-            const double tau_first = slot_tau(u1_prev, base_i, N, invN, pow2, S);
-            const double tau_last = slot_tau(u1_prev, base_i + nslots - 1, N, invN, pow2, S);
-#pragma unroll
-            for (int step = PG_FAST_NSEG / 2; step >= 1; step >>= 1) {
-                if (sm.cm[b_lo + step - 1] < tau_first) b_lo += step;
-                if (sm.cm[b_hi + step - 1] < tau_last) b_hi += step;
-            }
-            // (cm is padded with +inf, so both counts are <= nseg; a count of nseg means "past the last segment")
-            if (b_hi > nseg - 1) b_hi = nseg - 1;
-            // enumerate the non-empty source segments of [b_lo, b_hi] (a segment whose running max did not move owns no
-            // slot) by bisection jumps: the next one after carry c is #{b : cm[b] <= c}.  Bounded work however long the
-            // run of empty segments between two heavy particles is.
-            int b = b_lo;
-            while (ns <= PG_FGROUPS * PG_FSTAGE) {
-                const double c0 = b ? sm.cm[b - 1] : 0.0;
-                int nb = 0;
-#pragma unroll
-                for (int step = PG_FAST_NSEG / 2; step >= 1; step >>= 1)
-                    if (sm.cm[nb + step - 1] <= c0) nb += step;
-                if (nb + 1 <= PG_FAST_NSEG && sm.cm[nb] <= c0) ++nb;  // all PG_FAST_NSEG entries <= c0 cannot happen (cm pads with +inf or ends at S > c0)
-                if (nb > b_hi) break;
-                if (ns < PG_FGROUPS * PG_FSTAGE && tid == 0) {
-                    sm.cand_b[ns] = nb;
-                    sm.cand_ex[ns] = sm.u.tab.excl[nb];
-                    sm.cand_sc[ns] = sm.u.tab.scale[nb];
-                    sm.cand_cy[ns] = c0;
-                }
-                ++ns;
-                b = nb + 1;
-            }
-        }
-        PG_STAMP(2);
-        if (ns > 0 && ns <= PG_FGROUPS * PG_FSTAGE) {
-            // ---- common case: stage the numerators of PG_FSTAGE source segments at a time, back to back; they are
-            // non-decreasing across the window (running-max carry), so one branch-free lower bound per slot settles
-            // every slot that falls into the window
-            __syncthreads();
-            for (int k0w = 0; k0w < ns; k0w += PG_FSTAGE) {  // uniform
-                const int ng = ns - k0w < PG_FSTAGE ? ns - k0w : PG_FSTAGE;
-                int sb_idx[PG_FSTAGE] = {0, 0};
-                double sex[PG_FSTAGE] = {0.0, 0.0}, ssc[PG_FSTAGE] = {0.0, 0.0}, scy[PG_FSTAGE] = {0.0, 0.0};
-#pragma unroll
-                for (int g = 0; g < PG_FSTAGE; ++g) {
-                    if (g < ng) {
-                        sb_idx[g] = sm.cand_b[k0w + g];
-                        sex[g] = sm.cand_ex[k0w + g];
-                        ssc[g] = sm.cand_sc[k0w + g];
-                        scy[g] = sm.cand_cy[k0w + g];
-                    }
-                }
-                const double g_carry = scy[0];
-                // global loads first, then the barrier that frees the table / the previous window
-                ulonglong2 c01[PG_FSTAGE], c23[PG_FSTAGE];
-#pragma unroll
-                for (int g = 0; g < PG_FSTAGE; ++g) {
-                    if (g < ng) {
-                        const ulonglong2* src = reinterpret_cast<const ulonglong2*>(sb_prev.c1 + (int64_t)sb_idx[g] * PGAS_SEG) + 2 * tid;
-                        c01[g] = src[0];
-                        c23[g] = src[1];
-                    }
-                }
-                __syncthreads();
-#pragma unroll
-                for (int g = 0; g < PG_FSTAGE; ++g) {
-                    double4 v = make_double4(__builtin_inf(), __builtin_inf(), __builtin_inf(), __builtin_inf());
-                    if (g < ng) {
-                        const int64_t base_k = (int64_t)sb_idx[g] * PGAS_SEG;
-                        const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
-                        const int k0 = PG_PPT * tid;
-                        const double e0 = sex[g], s0 = ssc[g], cy = scy[g];
-                        if (k0 + 0 < n) v.x = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c01[g].x) * PGAS_FIX_INV), cy);
-                        if (k0 + 1 < n) v.y = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c01[g].y) * PGAS_FIX_INV), cy);
-                        if (k0 + 2 < n) v.z = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c23[g].x) * PGAS_FIX_INV), cy);
-                        if (k0 + 3 < n) v.w = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c23[g].y) * PGAS_FIX_INV), cy);
-                    }
-                    reinterpret_cast<double4*>(sm.u.num[g])[tid] = v;
-                }
-                __syncthreads();
-                PG_STAMP(3);
-                const double* __restrict__ num = &sm.u.num[0][0];
-                int pos[PG_PPT] = {0, 0, 0, 0};
-#pragma unroll
-                for (int step = PG_FSTAGE * PGAS_SEG / 2; step >= 1; step >>= 1) {
-#pragma unroll
-                    for (int j = 0; j < PG_PPT; ++j) {  // loads are unconditional so the four chains advance in lock step
-                        const int q = pos[j] + step;
-                        const int qc = q <= PG_FSTAGE * PGAS_SEG ? q : PG_FSTAGE * PGAS_SEG;
-                        const double v = num[qc - 1];
-                        pos[j] = (q <= PG_FSTAGE * PGAS_SEG && v < tau[j]) ? q : pos[j];
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < PG_PPT; ++j) {
-                    if (g_carry < tau[j] && pos[j] < ng * PGAS_SEG) {
-                        const int g = pos[j] >> 10, off = pos[j] & (PGAS_SEG - 1);
-                        const int64_t ai = (int64_t)(g == 0 ? sb_idx[0] : sb_idx[1]) * PGAS_SEG + off;
-                        a[j] = ai > N - 1 ? N - 1 : (int)ai;
-                    }
-                }
-            }
-        } else if (ns > PG_FGROUPS * PG_FSTAGE) {
-            // degenerate weights: per-slot bisection, segment level in LDS, particle level in global memory
-#pragma unroll
-            for (int j = 0; j < PG_PPT; ++j) {
-                int bs = 0;
-#pragma unroll
-                for (int step = PG_FAST_NSEG / 2; step >= 1; step >>= 1)
-                    if (sm.cm[bs + step - 1] < tau[j]) bs += step;
-                if (bs < nseg) {
-                    const double e0 = sm.u.tab.excl[bs], s0 = sm.u.tab.scale[bs], cy = bs ? sm.cm[bs - 1] : 0.0;
-                    const int64_t base_k = (int64_t)bs * PGAS_SEG;
-                    const int n = (N - base_k) < PGAS_SEG ? (int)(N - base_k) : PGAS_SEG;
-                    const uint64_t* __restrict__ c = sb_prev.c1 + base_k;
-                    int lo = 0, hi = n;
-                    while (lo < hi) {
-                        const int mid = (lo + hi) >> 1;
-                        const double v = __builtin_fmax(e0 + s0 * (pgas_u64_to_double(c[mid]) * PGAS_FIX_INV), cy);
-                        if (v < tau[j]) lo = mid + 1; else hi = mid;
-                    }
-                    const int64_t ai = base_k + lo;
-                    a[j] = ai > N - 1 ? N - 1 : (int)ai;
-                }
-            }
-        }
-        if (last_wg) {
-            // ancestor of the conditioned particle, published by workgroup 0 (src/PGAS.py:127)
-            __syncthreads();
-            if (tid == 0) {
-                unsigned long long g = 0;
-                int spins = 0;
-                for (; spins < (1 << 16); ++spins) {
-                    g = __hip_atomic_load(&sb_prev.hdr->ref_granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(g >> 32) == tag) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                sm.up.cnt[0] = ((unsigned)(g >> 32) == tag) ? (int)(unsigned)g : -1;
-            }
-            __syncthreads();
-            int ref_idx = sm.up.cnt[0];
-            if (ref_idx < 0) {  // uniform: the word never arrived -- draw the ancestor here
-                __syncthreads();
-                double ex2[1][GPW], sc2[1][GPW], cm2[1][GPW], S2[1];
-                upper_core<GPW, 1>(sm.up, sb_prev.segm + nsegp, sb_prev.segs + nsegp, 0, nseg, ex2, sc2, cm2, S2);
-                ref_idx = N - 1;
-                if ((S2[0] > 0.0) && (S2[0] < __builtin_inf()))
-                    ref_idx = cdf_count_block_recompute<GPW>(sm.up, ex2[0], sc2[0], cm2[0], nseg, N, u2_prev * S2[0], anc_in);
-            }
-#pragma unroll
-            for (int j = 0; j < PG_PPT; ++j)
-                if (base_i + slot_of(tid, j) == N - 1) a[j] = ref_idx;
-        }
-        PG_STAMP(4);
-        // ---- slot-major -> particle-major through LDS, ancestor trace, weight update
-        __syncthreads();
-    #pragma unroll
-        for (int j = 0; j < PG_PPT; ++j) {
-            sm.u.a[slot_of(tid, j)] = a[j];
-            if (base_i + slot_of(tid, j) < N) anc_out[base_i + slot_of(tid, j)] = a[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
-            const int64_t i = base_i + r * PG_BLK + tid;
-            if (i < N) lwp[r] = lnv[r] - sb_prev.laux[sm.u.a[r * PG_BLK + tid]];
-        }
-        PG_STAMP(5);
-        if (logw_out != nullptr) {
-#pragma unroll
-            for (int r = 0; r < PG_PPT; ++r) {
-                const int64_t i = base_i + r * PG_BLK + tid;
-                if (i < N) logw_out[i] = lwp[r];
-            }
-        }
-        __syncthreads();  // staging area -> ScanSmem reuse
-    }
-    if (mode & PG_RS_SCAN) {
-        double lw[2][PG_PPT];
-#pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
-            const size_t pi = (size_t)base_i + r * PG_BLK + tid;
-            const bool valid_p = pi < (size_t)N;
-            const double l1 = la_t[pi] + lwp[r];
-            lw[0][r] = valid_p ? l1 : -__builtin_inf();
-            lw[1][r] = valid_p ? l1 + h_t[pi] : -__builtin_inf();
-        }
-        PG_STAMP(6);
-        segment_scan<2, false>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segm_w, sb_next.segs_w);
-    }
-    PG_STAMP(7);
-}
-
 // ------------------------------------------------------------------------------------------
 // k_segscan: softmax scan of a plain weight vector (final index draw, src/PGAS.py:224)
 // ------------------------------------------------------------------------------------------
@@ -1700,7 +761,7 @@ __global__ __launch_bounds__(PG_BLK) void k_segscan(int N, const double* __restr
         const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
         lw[0][r] = i < N ? logw[i] : -__builtin_inf();
     }
-    segment_scan<1>(sm, lw, seg, sb.nsegp, sb.c1, nullptr, sb.segm_w, sb.segs_w);
+    segment_scan<1>(sm, lw, seg, sb.nsegp, sb.c1, nullptr, sb.segk_w, sb.segs_w);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1721,28 +782,6 @@ __global__ void k_backtrace(int Nl, int T, int nx, const double* __restrict__ x_
             // ancestor of particle b of time i, stored in row i-1 ... but row i-1 is indexed by the CHILD (time i) particle
             b = ar[(size_t)(i - 1) * Nl + bl];
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Standalone Filtering entry points (reference src/Filtering.py): systematic_SISR on a weight vector whose softmax scan
-// (k_segscan + k_upper) is already in sb, and reconstruct_trajectory from caller-owned traces.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PG_BLK) void k_systematic(DevModel md, double u, ScanBufs sb, int32_t* __restrict__ idx_out) {
-    __shared__ BackSmem sm;
-    int anc[PG_PPT];
-    Peers none;
-    none.world = 1;
-    resample_slots(md, sm, u, sb, none, blockIdx.x, idx_out, anc, false);
-}
-
-__global__ void k_backtrace_idx(int N, int T, int nx, const double* __restrict__ x_trace, const int32_t* __restrict__ anc_trace,
-                                int64_t idx, double* __restrict__ traj) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int64_t b = idx;
-    for (int i = T - 1; i >= 0; --i) {
-        for (int k = 0; k < nx; ++k) traj[(size_t)i * nx + k] = x_trace[((size_t)i * N + b) * nx + k];
-        if (i > 0) b = anc_trace[(size_t)(i - 1) * N + b];
     }
 }
 

@@ -1,0 +1,818 @@
+// pgas_resample.hip.h -- the weight recursion of the conditional-SMC sweep on gfx950: hierarchical CDF
+// (DESIGN.md section 4.4), systematic-resampling search (src/Filtering.py:28-35), ancestor draw of the
+// conditioned particle (src/PGAS.py:121-127), weight update (src/PGAS.py:137-147).
+//
+// Kernels:
+//   k_groups      one wave per (CDF, group of 64 segments): per-segment records (e, sc, m) and the group record (KG, TG)
+//   k_step<LOCAL> one launch per time step of the sweep: search of step t-1, weight update, softmax scans of step t,
+//                 ancestor workgroup.  LOCAL = every workgroup scans all groups itself from the raw segment partials
+//                 (single device, <= 1024 segments: no other launch on the critical path); otherwise the records come
+//                 from k_groups (any size, any number of ranks: a workgroup reads the <= 128 group records and the
+//                 segments of the one or two groups its slots fall into)
+//   k_count       #{k : num_k < u S} against a stored cumsum: final index (src/PGAS.py:224-225), reference ancestor of pgas_step
+//   k_back, k_back_corrected, k_systematic   the step API / src/Filtering.py entry points on the same search
+#pragma once
+
+#include "pgas_kernels.hip.h"
+
+#define PG_GRP PGAS_GRP
+#define PG_MAX_GRP (PG_MAX_NSEG / PG_GRP)
+#define PG_WIN_SEG 1024                      // segments a workgroup keeps in LDS (its search window)
+#define PG_WIN_GRP (PG_WIN_SEG / PG_GRP)
+#define PG_LOCAL_NSEG PG_WIN_SEG             // k_step<true>: the window is the whole device
+#define PG_FSTAGE 2                          // source segments staged at once (LDS budget: five workgroups per CU)
+#define PG_NCAND 8                           // staged candidates per workgroup before falling back to per-slot bisection
+#define PG_DEXP_ZERO (-32768)
+static_assert(PG_MAX_GRP <= 128, "top_scan_wave handles two blocks of 64 groups");
+
+// (rank, cdf, local segment) -> word of the gathered partial arrays
+__device__ __forceinline__ size_t partial_at(const ScanBufs& sb, int cdf, int b) {
+    return (size_t)(b / sb.nseg_l) * sb.rank_stride + (size_t)cdf * sb.nsegp + (size_t)(b % sb.nseg_l);
+}
+
+// Group level (one wave = one group, lane = segment): kk = kref of the lane's segment (-inf when it does not exist), ss its total.
+__device__ __forceinline__ void group_scan_wave(double kk, uint64_t ss, double& e, double& sc, double& m, double& Kg) {
+    const int lane = threadIdx.x & 63;
+    Kg = wave_max(kk);
+    sc = pgas_lvl_scale(kk, Kg);
+    const double t = sc * (pgas_u64_to_double(ss) * PGAS_FIX_INV);
+    const double incl = wave_scan_add(t);
+    const double up = __shfl_up(incl, 1);
+    e = lane ? up : 0.0;
+    m = wave_scan_max(e + t);
+}
+
+// Top level by one wave: lane l owns groups l and 64 + l (n1 <= 128).  Kg = -inf, Tg = 0 for groups that do not exist.
+__device__ __forceinline__ double top_scan_wave(int n1, const double (&Kg)[2], const double (&Tg)[2], double (&E)[2], double (&sig)[2],
+                                                double (&CM)[2]) {
+    const int lane = threadIdx.x & 63;
+    const double K = wave_max(__builtin_fmax(Kg[0], Kg[1]));
+    double TT[2], inc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        sig[h] = pgas_lvl_scale(Kg[h], K);
+        TT[h] = sig[h] * Tg[h];
+    }
+    inc[0] = wave_scan_add(TT[0]);
+    inc[1] = n1 > 64 ? wave_scan_add(TT[1]) : 0.0;
+    const double BT0 = readlane_f64(inc[0], 63);
+    double W[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const double up = __shfl_up(inc[h], 1);
+        E[h] = (h ? BT0 : 0.0) + (lane ? up : 0.0);
+        W[h] = (lane + 64 * h < n1) ? E[h] + TT[h] : 0.0;
+    }
+    CM[0] = wave_scan_max(W[0]);
+    const double M0 = readlane_f64(CM[0], 63);
+    CM[1] = M0;
+    double S = M0;
+    if (n1 > 64) {
+        CM[1] = __builtin_fmax(wave_scan_max(W[1]), M0);
+        S = readlane_f64(CM[1], 63);
+    }
+    return S;
+}
+
+__device__ __forceinline__ int dexp_of(double sc) { return sc > 0.0 ? (int)((pgas_d2bits(sc) >> 52) & 0x7ff) - 1023 : PG_DEXP_ZERO; }
+__device__ __forceinline__ double sc_of(int dexp) { return dexp == PG_DEXP_ZERO ? 0.0 : ldexp(1.0, dexp); }
+
+// CDF numerator of one particle: c = its integer cumsum inside the segment
+struct SegParams {
+    double e, sc, mp;     // segment: exclusive prefix inside the group, scale, running maximum before it
+    double E, sg, cp;     // group: exclusive prefix, scale, running maximum before it
+};
+__device__ __forceinline__ double num_of(uint64_t c, const SegParams& p) {
+    const double v = __builtin_fmax(p.mp, p.e + p.sc * (pgas_u64_to_double(c) * PGAS_FIX_INV));
+    return __builtin_fmax(p.cp, p.E + p.sg * v);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_groups
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_groups(int nseg, int ncdf, ScanBufs sb) {
+    const int lane = threadIdx.x & 63;
+    const int n1 = (nseg + PG_GRP - 1) / PG_GRP;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n1 * ncdf) return;
+    const int cdf = w / n1, g = w % n1;
+    const int b = g * PG_GRP + lane;
+    double kk = -__builtin_inf();
+    uint64_t ss = 0;
+    if (b < nseg) {
+        const size_t at = partial_at(sb, cdf, b);
+        kk = sb.segk[at];
+        ss = sb.segs[at];
+    }
+    double e, sc, m, Kg;
+    group_scan_wave(kk, ss, e, sc, m, Kg);
+    const int nb = nseg - g * PG_GRP < PG_GRP ? nseg - g * PG_GRP : PG_GRP;
+    const double Tg = readlane_f64(m, nb - 1);
+    if (b < nseg) {
+        const size_t o = (size_t)cdf * sb.nsegp_g + b;
+        sb.tab_e[o] = e;
+        sb.tab_sc[o] = sc;
+        sb.tab_m[o] = m;
+    }
+    if (lane == 0) {
+        sb.grp_K[cdf * PG_MAX_GRP + g] = Kg;
+        sb.grp_T[cdf * PG_MAX_GRP + g] = Tg;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Search window of a workgroup (256 threads) in LDS
+// ------------------------------------------------------------------------------------------
+template <bool LOCAL>
+struct WinSmemT {
+    double cm[PG_WIN_SEG];   // running maximum of the CDF at the end of every window segment, +inf beyond the window
+    union {
+        double num[PG_FSTAGE][PGAS_SEG];   // staged numerators
+        struct {
+            double e[PG_WIN_SEG], mp[PG_WIN_SEG];
+        } tab;                              // per-segment records of the window (valid until the first staging)
+        ScanSmem scan;
+        int a[PGAS_SEG];   // ancestors, slot-major -> particle-major exchange
+    } u;
+    short dexp[PG_WIN_SEG];   // log2 of the segment scales
+    double gE[PG_WIN_GRP], gS[PG_WIN_GRP], gCP[PG_WIN_GRP];   // window groups: E, sigma, CM of the group before
+    double topCM[LOCAL ? 1 : PG_MAX_GRP], topE[LOCAL ? 1 : PG_MAX_GRP], topS[LOCAL ? 1 : PG_MAX_GRP];
+    double grK[PG_WIN_GRP], grT[PG_WIN_GRP];   // LOCAL: group records found by the waves
+    int cand_b[PG_NCAND];
+    double cand_cy[PG_NCAND];
+    SegParams cand_p[PG_NCAND];
+    double S;
+    int g_lo, g_hi;
+    int cnt[2];
+    unsigned long long wsum[PG_BLK / 64];
+};
+
+// Fills the window of CDF `cdf` for thresholds tau in [U_first S, U_last S].
+// LOCAL: the window is the whole device (nseg <= 1024): every wave scans four groups from the raw partials.
+// otherwise: the group records of k_groups give the top level; the window holds the groups [g_lo, g_hi] (at most 16).
+// Out: S, first global segment of the window, number of window segments; returns false when the thresholds span more than the
+// window can hold (the caller then searches slot by slot through global memory).
+template <bool LOCAL>
+__device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs& sb, int cdf, int nseg, double U_first, double U_last,
+                                            double& S, int& win_b0, int& nwin) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n1 = (nseg + PG_GRP - 1) / PG_GRP;
+    if constexpr (LOCAL) {
+        double mreg[PG_WIN_GRP / 4];
+#pragma unroll
+        for (int e4 = 0; e4 < PG_WIN_GRP / 4; ++e4) {
+            const int g = wave + 4 * e4, b = (g << 6) + lane;
+            double kk = -__builtin_inf();
+            uint64_t ss = 0;
+            if (b < nseg) {
+                const size_t at = partial_at(sb, cdf, b);
+                kk = sb.segk[at];
+                ss = sb.segs[at];
+            }
+            double e, sc, m, Kg;
+            group_scan_wave(kk, ss, e, sc, m, Kg);
+            const double upm = __shfl_up(m, 1);
+            sm.u.tab.e[b] = e;
+            sm.u.tab.mp[b] = lane ? upm : 0.0;
+            sm.dexp[b] = (short)dexp_of(sc);
+            mreg[e4] = m;
+            int nb = nseg - g * PG_GRP;
+            nb = nb < 1 ? 1 : (nb > PG_GRP ? PG_GRP : nb);
+            const double Tg = readlane_f64(m, nb - 1);
+            if (lane == 0) {
+                sm.grK[g] = Kg;
+                sm.grT[g] = Tg;
+            }
+        }
+        __syncthreads();
+        const double Kg2[2] = {lane < n1 ? sm.grK[lane & (PG_WIN_GRP - 1)] : -__builtin_inf(), -__builtin_inf()};
+        const double Tg2[2] = {lane < n1 ? sm.grT[lane & (PG_WIN_GRP - 1)] : 0.0, 0.0};
+        double E[2], sig[2], CM[2];
+        S = top_scan_wave(n1, Kg2, Tg2, E, sig, CM);
+#pragma unroll
+        for (int e4 = 0; e4 < PG_WIN_GRP / 4; ++e4) {
+            const int g = wave + 4 * e4, b = (g << 6) + lane;
+            const double Eg = readlane_f64(E[0], g), sg = readlane_f64(sig[0], g), cpr = readlane_f64(CM[0], g ? g - 1 : 0);
+            const double cp = g ? cpr : 0.0;
+            sm.cm[b] = b < nseg ? __builtin_fmax(cp, Eg + sg * mreg[e4]) : __builtin_inf();
+        }
+        if (wave == 0) {
+            const double upc = __shfl_up(CM[0], 1);
+            if (lane < PG_WIN_GRP) {
+                sm.gE[lane] = E[0];
+                sm.gS[lane] = sig[0];
+                sm.gCP[lane] = lane ? upc : 0.0;
+            }
+        }
+        __syncthreads();
+        win_b0 = 0;
+        nwin = nseg;
+        (void)U_first;
+        (void)U_last;
+        return true;
+    } else {
+        if (wave == 0) {
+            double Kg2[2], Tg2[2], E[2], sig[2], CM[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int g = lane + 64 * h;
+                Kg2[h] = g < n1 ? sb.grp_K[cdf * PG_MAX_GRP + g] : -__builtin_inf();
+                Tg2[h] = g < n1 ? sb.grp_T[cdf * PG_MAX_GRP + g] : 0.0;
+            }
+            const double Sv = top_scan_wave(n1, Kg2, Tg2, E, sig, CM);
+            const double tf = U_first * Sv, tl = U_last * Sv;
+            int clo = 0, chi = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int g = lane + 64 * h;
+                if (g < n1) {
+                    sm.topCM[g] = CM[h];
+                    sm.topE[g] = E[h];
+                    sm.topS[g] = sig[h];
+                }
+                clo += __popcll(__ballot(g < n1 && CM[h] < tf));
+                chi += __popcll(__ballot(g < n1 && CM[h] < tl));
+            }
+            if (lane == 0) {
+                sm.S = Sv;
+                sm.g_lo = clo;
+                sm.g_hi = chi > n1 - 1 ? n1 - 1 : chi;
+            }
+        }
+        __syncthreads();
+        S = sm.S;
+        const int g_lo = sm.g_lo, g_hi = sm.g_hi;
+        int ngw = g_hi - g_lo + 1;   // <= 0 when every threshold lies beyond the total (cannot happen for U < 1, kept safe)
+        const bool covered = ngw <= PG_WIN_GRP;
+        ngw = ngw < 0 ? 0 : (ngw > PG_WIN_GRP ? PG_WIN_GRP : ngw);
+        win_b0 = g_lo * PG_GRP;
+        nwin = ngw * PG_GRP < nseg - win_b0 ? ngw * PG_GRP : nseg - win_b0;
+        if (nwin < 0) nwin = 0;
+        const size_t o = (size_t)cdf * sb.nsegp_g;
+#pragma unroll
+        for (int i = 0; i < PG_WIN_SEG / PG_BLK; ++i) {
+            const int gw = wave + 4 * i, wb = (gw << 6) + lane, g = g_lo + gw, b = win_b0 + wb;
+            double cmv = __builtin_inf();
+            if (gw < ngw) {   // wave-uniform
+                double e = 0.0, sc = 0.0, m = 0.0;
+                if (b < nseg) {
+                    e = sb.tab_e[o + b];
+                    sc = sb.tab_sc[o + b];
+                    m = sb.tab_m[o + b];
+                }
+                const double upm = __shfl_up(m, 1);
+                const double Eg = sm.topE[g], sg = sm.topS[g], cp = g ? sm.topCM[g - 1] : 0.0;
+                if (b < nseg) cmv = __builtin_fmax(cp, Eg + sg * m);
+                sm.u.tab.e[wb] = e;
+                sm.u.tab.mp[wb] = lane ? upm : 0.0;
+                sm.dexp[wb] = (short)dexp_of(sc);
+                if (lane == 0) {
+                    sm.gE[gw] = Eg;
+                    sm.gS[gw] = sg;
+                    sm.gCP[gw] = cp;
+                }
+            }
+            sm.cm[wb] = cmv;
+        }
+        __syncthreads();
+        return covered;
+    }
+}
+
+// branch-free lower bound over the +inf padded window: #{wb : cm[wb] < tau}
+template <class SM>
+__device__ __forceinline__ int win_lower_bound(const SM& sm, double tau) {
+    int p = 0;
+#pragma unroll
+    for (int step = PG_WIN_SEG / 2; step >= 1; step >>= 1)
+        if (sm.cm[p + step - 1] < tau) p += step;
+    return p;
+}
+
+template <class SM>
+__device__ __forceinline__ SegParams win_params(const SM& sm, int wb) {
+    SegParams p;
+    p.e = sm.u.tab.e[wb];
+    p.sc = sc_of(sm.dexp[wb]);
+    p.mp = sm.u.tab.mp[wb];
+    p.E = sm.gE[wb >> 6];
+    p.sg = sm.gS[wb >> 6];
+    p.cp = sm.gCP[wb >> 6];
+    return p;
+}
+
+__device__ __forceinline__ int seg_count(int N, int b) {
+    const int64_t base = (int64_t)b * PGAS_SEG;
+    return (N - base) < PGAS_SEG ? (int)(N - base) : PGAS_SEG;
+}
+
+// c1 data of GLOBAL source segment bs (this device's buffer, or a peer's through its xGMI mapping)
+__device__ __forceinline__ const uint64_t* c1_segment(const ScanBufs& sb, const Peers& pr, int bs) {
+    return pr.world > 1 ? pr.c1[bs / pr.nseg_l] + (size_t)(bs % pr.nseg_l) * PGAS_SEG : sb.c1 + (size_t)bs * PGAS_SEG;
+}
+
+// first k of segment b with num_k >= tau (n when there is none)
+__device__ __forceinline__ int seg_lower_bound(const uint64_t* __restrict__ c, int n, const SegParams& p, double tau) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (num_of(c[mid], p) < tau) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one slot through the global tables (thresholds outside the window: heavily degenerate weights only)
+template <class SM>
+__device__ __forceinline__ int slot_search_global(const SM& sm, const ScanBufs& sb, const Peers& pr, int cdf, int nseg, int N, double tau) {
+    const int n1 = (nseg + PG_GRP - 1) / PG_GRP;
+    int lo = 0, hi = n1;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sm.topCM[mid] < tau) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= n1) return N - 1;
+    const int g = lo;
+    SegParams p;
+    p.E = sm.topE[g];
+    p.sg = sm.topS[g];
+    p.cp = g ? sm.topCM[g - 1] : 0.0;
+    const size_t o = (size_t)cdf * sb.nsegp_g + (size_t)g * PG_GRP;
+    const int nb = nseg - g * PG_GRP < PG_GRP ? nseg - g * PG_GRP : PG_GRP;
+    lo = 0, hi = nb - 1;   // the group's last segment reaches W_g >= tau
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (__builtin_fmax(p.cp, p.E + p.sg * sb.tab_m[o + mid]) < tau) lo = mid + 1; else hi = mid;
+    }
+    const int b = g * PG_GRP + lo;
+    p.e = sb.tab_e[o + lo];
+    p.sc = sb.tab_sc[o + lo];
+    p.mp = lo ? sb.tab_m[o + lo - 1] : 0.0;
+    const int64_t ai = (int64_t)b * PGAS_SEG + seg_lower_bound(c1_segment(sb, pr, b), seg_count(N, b), p, tau);
+    return ai > N - 1 ? N - 1 : (int)ai;
+}
+
+// Resampling slot j of thread tid inside its workgroup's 1024 slots: lanes of a wave take consecutive slots (for every j),
+// so that the lower-bound probes of a wave fall on consecutive LDS words (no bank conflicts).
+__device__ __forceinline__ int slot_of(int tid, int j) { return ((tid >> 6) << 8) + (j << 6) + (tid & 63); }
+
+__device__ __forceinline__ double slot_U(double u1, int64_t i, int N, double invN, bool pow2) {
+    const double x = u1 + (double)i;
+    return pow2 ? x * invN : x / (double)N;  // exact either way when N is a power of two
+}
+
+// ------------------------------------------------------------------------------------------
+// Systematic-resampling search (src/Filtering.py:28-35) for the 1024 slots of local segment `seg`: a[j] = ancestor of
+// slot slot_of(tid, j), a GLOBAL particle index.  md.p0 / md.Ng / md.nseg_g place the device's shard in the global
+// particle range (single device: 0 / N / nseg).  Leaves LDS free for reuse after a trailing barrier of the caller.
+// ------------------------------------------------------------------------------------------
+template <bool LOCAL>
+__device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOCAL>& sm, double u1, const ScanBufs& sb, const Peers& pr,
+                                                int seg, int (&a)[PG_PPT]) {
+    const int tid = threadIdx.x;
+    const int nseg = md.nseg_g, N = md.Ng;
+    const bool pow2 = (N & (N - 1)) == 0;
+    const double invN = 1.0 / (double)N;
+    const int64_t loc_i = (int64_t)seg * PGAS_SEG;
+    const int64_t base_i = md.p0 + loc_i;
+    const int nslots = (md.N - loc_i) < PGAS_SEG ? (int)(md.N - loc_i) : PGAS_SEG;
+    const double U_first = slot_U(u1, base_i, N, invN, pow2), U_last = slot_U(u1, base_i + nslots - 1, N, invN, pow2);
+    double S;
+    int win_b0, nwin;
+    const bool covered = window_head<LOCAL>(sm, sb, 0, nseg, U_first, U_last, S, win_b0, nwin);
+    PG_STAMP(1);
+    const bool valid = (S > 0.0) && (S < __builtin_inf());
+    double tau[PG_PPT];
+#pragma unroll
+    for (int j = 0; j < PG_PPT; ++j) {
+        const int64_t i = base_i + slot_of(tid, j);
+        tau[j] = slot_U(u1, i, N, invN, pow2) * S;
+        a[j] = valid ? N - 1 : (int)(i < N ? i : N - 1);
+    }
+    int ns = 0;   // non-empty source segments of this workgroup's slots, counted up to PG_NCAND + 1
+    if (valid && covered) {   // uniform
+        const double tau_first = U_first * S, tau_last = U_last * S;
+        int b_lo = win_lower_bound(sm, tau_first), b_hi = win_lower_bound(sm, tau_last);
+        if (b_hi > nwin - 1) b_hi = nwin - 1;   // slots beyond the last segment keep a = N-1
+        // enumerate the non-empty source segments of [b_lo, b_hi] (a segment whose running max did not move owns no slot)
+        // by bisection jumps: the next one after carry c is #{b : cm[b] <= c}.  Bounded work however long the run of
+        // empty segments between two heavy particles is.
+        int b = b_lo;
+        while (ns <= PG_NCAND) {
+            const double c0 = b ? sm.cm[b - 1] : (win_b0 ? sm.gCP[0] : 0.0);
+            int nb = 0;
+#pragma unroll
+            for (int step = PG_WIN_SEG / 2; step >= 1; step >>= 1)
+                if (sm.cm[nb + step - 1] <= c0) nb += step;
+            if (nb + 1 <= PG_WIN_SEG && sm.cm[nb] <= c0) ++nb;
+            if (nb > b_hi) break;
+            if (ns < PG_NCAND && tid == 0) {
+                sm.cand_b[ns] = win_b0 + nb;
+                sm.cand_cy[ns] = c0;
+                sm.cand_p[ns] = win_params(sm, nb);
+            }
+            ++ns;
+            b = nb + 1;
+        }
+    }
+    PG_STAMP(2);
+    if (valid && covered && ns > 0 && ns <= PG_NCAND) {
+        // ---- common case: stage the numerators of PG_FSTAGE source segments at a time, back to back; they are
+        // non-decreasing across the window (running-max carry), so one branch-free lower bound per slot settles
+        // every slot that falls into the window
+        __syncthreads();
+        for (int k0w = 0; k0w < ns; k0w += PG_FSTAGE) {  // uniform
+            const int ng = ns - k0w < PG_FSTAGE ? ns - k0w : PG_FSTAGE;
+            int sb_idx[PG_FSTAGE] = {0, 0};
+            SegParams sp[PG_FSTAGE];
+#pragma unroll
+            for (int g = 0; g < PG_FSTAGE; ++g)
+                if (g < ng) {
+                    sb_idx[g] = sm.cand_b[k0w + g];
+                    sp[g] = sm.cand_p[k0w + g];
+                }
+            const double g_carry = sm.cand_cy[k0w];
+            // global loads first, then the barrier that frees the table / the previous window
+            ulonglong2 c01[PG_FSTAGE], c23[PG_FSTAGE];
+#pragma unroll
+            for (int g = 0; g < PG_FSTAGE; ++g)
+                if (g < ng) {
+                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(c1_segment(sb, pr, sb_idx[g])) + 2 * tid;
+                    c01[g] = src[0];
+                    c23[g] = src[1];
+                }
+            __syncthreads();
+#pragma unroll
+            for (int g = 0; g < PG_FSTAGE; ++g) {
+                double4 v = make_double4(__builtin_inf(), __builtin_inf(), __builtin_inf(), __builtin_inf());
+                if (g < ng) {
+                    const int n = seg_count(N, sb_idx[g]);
+                    const int k0 = PG_PPT * tid;
+                    if (k0 + 0 < n) v.x = num_of(c01[g].x, sp[g]);
+                    if (k0 + 1 < n) v.y = num_of(c01[g].y, sp[g]);
+                    if (k0 + 2 < n) v.z = num_of(c23[g].x, sp[g]);
+                    if (k0 + 3 < n) v.w = num_of(c23[g].y, sp[g]);
+                }
+                reinterpret_cast<double4*>(sm.u.num[g])[tid] = v;
+            }
+            __syncthreads();
+            PG_STAMP(3);
+            const double* __restrict__ num = &sm.u.num[0][0];
+            int pos[PG_PPT] = {0, 0, 0, 0};
+#pragma unroll
+            for (int step = PG_FSTAGE * PGAS_SEG / 2; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int j = 0; j < PG_PPT; ++j) {  // loads are unconditional so the four chains advance in lock step
+                    const int q = pos[j] + step;
+                    const int qc = q <= PG_FSTAGE * PGAS_SEG ? q : PG_FSTAGE * PGAS_SEG;
+                    const double v = num[qc - 1];
+                    pos[j] = (q <= PG_FSTAGE * PGAS_SEG && v < tau[j]) ? q : pos[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < PG_PPT; ++j) {
+                if (g_carry < tau[j] && pos[j] < ng * PGAS_SEG) {
+                    const int g = pos[j] >> 10, off = pos[j] & (PGAS_SEG - 1);
+                    const int64_t ai = (int64_t)(g == 0 ? sb_idx[0] : sb_idx[1]) * PGAS_SEG + off;
+                    a[j] = ai > N - 1 ? N - 1 : (int)ai;
+                }
+            }
+        }
+    } else if (valid && covered && ns > PG_NCAND) {
+        // degenerate weights: per-slot bisection, segment level in LDS, particle level in global memory
+#pragma unroll
+        for (int j = 0; j < PG_PPT; ++j) {
+            const int wb = win_lower_bound(sm, tau[j]);
+            if (wb < nwin) {
+                const SegParams p = win_params(sm, wb);
+                const int b = win_b0 + wb;
+                const int64_t ai = (int64_t)b * PGAS_SEG + seg_lower_bound(c1_segment(sb, pr, b), seg_count(N, b), p, tau[j]);
+                a[j] = ai > N - 1 ? N - 1 : (int)ai;
+            }
+        }
+    } else if (valid && !covered) {
+        if constexpr (!LOCAL) {
+#pragma unroll
+            for (int j = 0; j < PG_PPT; ++j) a[j] = slot_search_global(sm, sb, pr, 0, nseg, N, tau[j]);
+        }
+    }
+}
+
+// Search + the bookkeeping every caller needs: conditioned slot, slot-major -> particle-major through LDS, ancestor trace.
+template <bool LOCAL>
+__device__ __forceinline__ void resample_slots(const DevModel& md, WinSmemT<LOCAL>& sm, double u1, const ScanBufs& sb, const Peers& pr, int seg,
+                                               int32_t* __restrict__ anc_out, int (&anc_pm)[PG_PPT], int ref_idx /* < 0: none */) {
+    const int tid = threadIdx.x;
+    int a[PG_PPT];
+    resample_search<LOCAL>(md, sm, u1, sb, pr, seg, a);
+    const int64_t loc_i = (int64_t)seg * PGAS_SEG, base_i = md.p0 + loc_i;
+#pragma unroll
+    for (int j = 0; j < PG_PPT; ++j)
+        if (ref_idx >= 0 && base_i + slot_of(tid, j) == md.Ng - 1) a[j] = ref_idx;  // src/PGAS.py:127
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PG_PPT; ++j) {
+        sm.u.a[slot_of(tid, j)] = a[j];
+        if (loc_i + slot_of(tid, j) < md.N) anc_out[loc_i + slot_of(tid, j)] = a[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) anc_pm[r] = sm.u.a[r * PG_BLK + tid];  // ancestor of local particle loc_i + r*BLK + tid
+}
+
+// ------------------------------------------------------------------------------------------
+// #{k : num_k < U S} of CDF `cdf` by one workgroup, the searchsorted of src/PGAS.py:122-124 / :225, min'ed with N-1.
+//   stored:    the per-particle cumsum comes from a buffer (cbuf of this device, or cb_ranks[r] through peer mappings)
+//   otherwise: it is REBUILT for the one segment that matters from what the sweep keeps in HBM (AncIn, below)
+// ------------------------------------------------------------------------------------------
+// The ancestor CDF of a step (src/PGAS.py:117-124) is read in ONE segment only: the one the reference particle's uniform falls
+// into.  The sweep therefore never stores its per-particle cumsum; the workgroup that draws the ancestor rebuilds that
+// segment -- lw2_i = (la_s[i] + logw_{s-1}[i]) + h_s[i] with logw_{s-1}[i] = ln_{s-1}[i] - la_{s-1}[a_{s-1}[i]] (0 for s = 1),
+// the same expressions, the segment's stored reference k, the same fixed-point numerators and an exact integer cumsum --
+// and counts against it.  Bit-identical to a stored version.
+struct AncIn {
+    int64_t row_s;      // offset of row s in la/h/ln buffers (s * np_l)
+    int64_t row_p;      // offset of row s-1, or -1 for s = 1
+    int64_t anc_row_p;  // offset of the ancestors of step s-1 in anc_trace ((s-2) * N_l)
+};
+
+template <bool LOCAL>
+__device__ __forceinline__ int cdf_count_wg(WinSmemT<LOCAL>& sm, const ScanBufs& sb, const Peers& pr, int cdf, int nseg, int N, double U,
+                                            const uint64_t* __restrict__ cbuf, const uint64_t* const* cb_ranks, const AncIn* rebuild) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    double S;
+    int win_b0, nwin;
+    window_head<LOCAL>(sm, sb, cdf, nseg, U, U, S, win_b0, nwin);   // one threshold: always covered
+    if (!((S > 0.0) && (S < __builtin_inf()))) return N - 1;
+    const double tau = U * S;
+    const int wb = win_lower_bound(sm, tau);
+    if (wb >= nwin) return N - 1;
+    const SegParams p = win_params(sm, wb);
+    const int b = win_b0 + wb;
+    const int n = seg_count(N, b);
+    const int64_t base = (int64_t)b * PGAS_SEG;
+    if (tid == 0) sm.cnt[0] = 0;
+    int k = 0;
+    if (rebuild == nullptr) {
+        const uint64_t* __restrict__ cseg = (cb_ranks && pr.world > 1) ? cb_ranks[b / pr.nseg_l] + (size_t)(b % pr.nseg_l) * PGAS_SEG : cbuf + base;
+        __syncthreads();
+        for (int i = tid; i < n; i += PG_BLK) k += (num_of(cseg[i], p) < tau) ? 1 : 0;
+    } else {
+        // owner rank of the segment and its local rows
+        const int r = pr.world > 1 ? b / pr.nseg_l : 0;
+        const int64_t lbase = base - (int64_t)r * pr.Nl;   // local particle index of the segment's first particle on rank r
+        const double kref = sb.segk[partial_at(sb, cdf, b)];
+        const double* __restrict__ la_s = pr.la[r] + rebuild->row_s;
+        const double* __restrict__ h_s = pr.h[r] + rebuild->row_s;
+        double arg[PG_PPT], ev[PG_PPT];
+#pragma unroll
+        for (int j = 0; j < PG_PPT; ++j) {
+            const int i = PG_PPT * tid + j;
+            double lw2 = -__builtin_inf();
+            if (i < n) {
+                const int64_t li = lbase + i;
+                double logw = 0.0;
+                if (rebuild->row_p >= 0) {
+                    const int ap = pr.anc[r][rebuild->anc_row_p + li];   // GLOBAL index of the ancestor at step s-1
+                    const int ra = pr.world > 1 ? ap / pr.Nl : 0;
+                    logw = pr.ln[r][rebuild->row_p + li] - pr.la[ra][rebuild->row_p + (ap - (int64_t)ra * pr.Nl)];
+                }
+                const double l1 = la_s[li] + logw;
+                lw2 = l1 + h_s[li];
+            }
+            arg[j] = pgas_seg_arg(lw2, kref);
+        }
+        pgas_exp_n(arg, ev, PG_PPT);
+        uint64_t loc[PG_PPT], run = 0;
+#pragma unroll
+        for (int j = 0; j < PG_PPT; ++j) {
+            run += (ev[j] > 0.0) ? pgas_double_to_u64(__builtin_rint(ev[j] * PGAS_FIX_SCALE)) : 0ull;
+            loc[j] = run;
+        }
+        const uint64_t incl = wave_incl_scan_u64(run);
+        if (lane == 63) sm.wsum[wave] = incl;
+        __syncthreads();
+        uint64_t off = incl - run;
+#pragma unroll
+        for (int v = 0; v < PG_BLK / 64; ++v)
+            if (v < wave) off += sm.wsum[v];
+#pragma unroll
+        for (int j = 0; j < PG_PPT; ++j) k += (PG_PPT * tid + j < n && num_of(off + loc[j], p) < tau) ? 1 : 0;
+    }
+    k = wave_sum_i(k);
+    if (lane == 0 && k) atomicAdd(&sm.cnt[0], k);
+    __syncthreads();
+    const int64_t res = base + sm.cnt[0];
+    return res > N - 1 ? N - 1 : (int)res;
+}
+
+// k_count: one workgroup; what = 0: reference ancestor of pgas_step (CDF 1 against c2) -> hdr->ref_idx,
+//                          what = 1: final index (CDF 0 against c1)                    -> hdr->final_idx
+__global__ __launch_bounds__(PG_BLK) void k_count(int N, int nseg, ScanBufs sb, Peers pr, int what, double u) {
+    __shared__ WinSmemT<false> sm;
+    const int cdf = what == 0 ? 1 : 0;
+    const int r = cdf_count_wg<false>(sm, sb, pr, cdf, nseg, N, u, cdf ? sb.c2 : sb.c1, cdf ? pr.c2 : pr.c1, nullptr);
+    if (threadIdx.x == 0) {
+        if (what == 0) sb.hdr->ref_idx = r; else sb.hdr->final_idx = r;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// step API back half: systematic resampling search + weight update (src/PGAS.py:137-147)
+// ------------------------------------------------------------------------------------------
+template <int NX>
+__global__ __launch_bounds__(PG_BLK) void k_back(DevModel md, int t, double u1, const double* __restrict__ x_cur, ScanBufs sb, Peers pr,
+                                                  int32_t* __restrict__ anc_out, double* __restrict__ logw_out) {
+    __shared__ WinSmemT<false> sm;
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    double xv[PG_PPT][NX];
+    load_particles<NX>(md, x_cur, seg, xv);
+    int anc[PG_PPT];
+    resample_slots<false>(md, sm, u1, sb, pr, seg, anc_out, anc, sb.hdr->ref_idx);
+    const double* __restrict__ yt = md.y + (size_t)t * md.ny;
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) {
+        const int64_t i = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
+        if (i < md.N) logw_out[i] = loglik<NX>(md, yt, xv[r]) - sb.laux[anc[r]];
+    }
+}
+
+// k_back_corrected: the second half of a step in the CORRECTED mode (resample_before_propagate; quirk Q1 removed):
+//   a = systematic resampling search,  x_new_i = aux[a_i] + L_S z_i  (conditioned particle = ref_t),
+//   logw_new_i = log p(y_t | x_new_i) - l_aux[a_i].
+// aux holds the transition means k_front stored; the noise z_i is the same Philox draw the default mode uses for
+// particle i at time t, so the two modes differ only in which mean the noise is added to.
+template <int NX>
+__global__ __launch_bounds__(PG_BLK) void k_back_corrected(DevModel md, TransParams tp, int t, uint64_t seed, double u1,
+                                                            const double* __restrict__ aux, const double* __restrict__ ref_t, ScanBufs sb, Peers pr,
+                                                            int32_t* __restrict__ anc_out, double* __restrict__ x_new,
+                                                            double* __restrict__ logw_out) {
+    __shared__ WinSmemT<false> sm;
+    const int seg = blockIdx.x, tid = threadIdx.x;
+    int anc[PG_PPT];
+    resample_slots<false>(md, sm, u1, sb, pr, seg, anc_out, anc, sb.hdr->ref_idx);
+    const double* __restrict__ yt = md.y + (size_t)t * md.ny;
+    double z0[PG_PPT], z1[PG_PPT];
+    {
+        pgas_u32x4 w[PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
+            w[r] = pgas_rng_block(seed, PGAS_STREAM_PROP, 0u, (uint32_t)t, (uint64_t)(md.p0 + pi));
+        }
+        pgas_normal_pair_n(w, z0, z1, PG_PPT);
+    }
+    double xn[PG_PPT][NX];
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) {
+        const int64_t pi = (int64_t)seg * PGAS_SEG + r * PG_BLK + tid;
+        const int src = pi < md.N ? anc[r] : 0;
+        const double z[2] = {z0[r], z1[r]};
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            double v = aux[(size_t)src * NX + k];
+#pragma unroll
+            for (int l = 0; l <= k; ++l) v = PGAS_FMA(tp.LS[k * NX + l], z[l], v);
+            xn[r][k] = (md.p0 + pi == md.Ng - 1) ? ref_t[k] : v;
+        }
+        if (pi < md.N) logw_out[pi] = loglik<NX>(md, yt, xn[r]) - sb.laux[src];
+    }
+    store_particles<NX>(md, x_new, seg, xn);
+}
+
+// systematic_SISR (src/Filtering.py:6-37) on a weight vector whose segment scans (k_segscan) and group records (k_groups) are in sb
+__global__ __launch_bounds__(PG_BLK) void k_systematic(DevModel md, double u, ScanBufs sb, Peers pr, int32_t* __restrict__ idx_out) {
+    __shared__ WinSmemT<false> sm;
+    int anc[PG_PPT];
+    resample_slots<false>(md, sm, u, sb, pr, blockIdx.x, idx_out, anc, -1);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_step: one launch per time step of the sweep (condSequentialMonteCarlo.__call__, src/PGAS.py:199-221).
+// Launch t in [1, T]: resamples step t-1 (t > 1: search, ancestors, logw_{t-1} = ln_{t-1} - la_{t-1}[a]) and scans step t
+// (t < T: both softmaxes, segment partials for the group scans of the next launch).
+//
+// Grid = nseg + 1 workgroups.  Workgroup 0 only draws the reference particle's ancestor (src/PGAS.py:121-127) and publishes
+// it as one 8-byte {launch tag, index} word; workgroup b + 1 owns segment b.  The workgroup that owns the conditioned
+// particle reads that word late (after its own search).  Workgroup 0 never waits for anyone, so the hand-off cannot
+// deadlock whatever the dispatch order; if the word has not arrived within the spin budget the owner computes the
+// ancestor itself (same code, same result).
+// ------------------------------------------------------------------------------------------
+#define PG_RS_SEARCH 1  // resample step t-1 (sb_prev valid) and form logw_{t-1}; otherwise logw_{t-1} = 0 (t = 1)
+#define PG_RS_SCAN 2    // scan step t's weights into sb_next; otherwise only emit logw_{t-1} (after the last step)
+
+struct StepArgs {
+    int t, mode;
+    unsigned tag;
+    double u1_prev, u2_prev;
+    const double* la_t;      // (np) row t of la_buf, this device
+    const double* h_t;       // (np) row t of h_buf
+    const double* ln_prev;   // (np) row t-1 of ln_buf
+    int64_t row_prev;        // offset of row t-1 in la/h/ln buffers (peer reads of log p(y_{t-1} | aux_{t-1}) of remote ancestors)
+    AncIn anc_in;            // rows the ancestor workgroup rebuilds from (s = t-1)
+    int32_t* anc_out;        // (N) ancestors of step t-1
+    double* logw_out;        // optional (N) logw_{t-1}
+};
+
+template <bool LOCAL>
+__global__ __launch_bounds__(PG_BLK, 5) void k_step(DevModel md, StepArgs ar, ScanBufs sb_prev, ScanBufs sb_next, Peers pr) {
+    __shared__ WinSmemT<LOCAL> sm;
+    const int tid = threadIdx.x;
+    const int N = md.N;
+    if (blockIdx.x == 0) {  // ---- ancestor workgroup
+        if (!(ar.mode & PG_RS_SEARCH)) return;
+        const int r = cdf_count_wg<LOCAL>(sm, sb_prev, pr, 1, md.nseg_g, md.Ng, ar.u2_prev, nullptr, nullptr, &ar.anc_in);
+        if (tid == 0)
+            __hip_atomic_store(&sb_prev.hdr->ref_granule, ((unsigned long long)ar.tag << 32) | (unsigned)r, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int seg = blockIdx.x - 1;
+    const int64_t base_i = (int64_t)seg * PGAS_SEG;
+    PG_STAMP(0);
+    // own-particle inputs first: their latency overlaps the scans below
+    double lnv[PG_PPT];
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) lnv[r] = (ar.mode & PG_RS_SEARCH) ? ar.ln_prev[(size_t)base_i + r * PG_BLK + tid] : 0.0;
+    double lwp[PG_PPT] = {0.0, 0.0, 0.0, 0.0};
+    if (ar.mode & PG_RS_SEARCH) {
+        int a[PG_PPT];
+        resample_search<LOCAL>(md, sm, ar.u1_prev, sb_prev, pr, seg, a);
+        const bool last_wg = md.p0 + base_i + PGAS_SEG >= md.Ng;  // uniform: owns the conditioned particle
+        if (last_wg) {
+            // ancestor of the conditioned particle, published by workgroup 0 (src/PGAS.py:127)
+            __syncthreads();
+            if (tid == 0) {
+                unsigned long long g = 0;
+                int spins = 0;
+                for (; spins < (1 << 16); ++spins) {
+                    g = __hip_atomic_load(&sb_prev.hdr->ref_granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((unsigned)(g >> 32) == ar.tag) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                sm.cnt[1] = ((unsigned)(g >> 32) == ar.tag) ? (int)(unsigned)g : -1;
+            }
+            __syncthreads();
+            int ref_idx = sm.cnt[1];
+            if (ref_idx < 0) {  // uniform: the word never arrived -- draw the ancestor here
+                __syncthreads();
+                ref_idx = cdf_count_wg<LOCAL>(sm, sb_prev, pr, 1, md.nseg_g, md.Ng, ar.u2_prev, nullptr, nullptr, &ar.anc_in);
+            }
+#pragma unroll
+            for (int j = 0; j < PG_PPT; ++j)
+                if (md.p0 + base_i + slot_of(tid, j) == md.Ng - 1) a[j] = ref_idx;
+        }
+        PG_STAMP(4);
+        // ---- slot-major -> particle-major through LDS, ancestor trace, weight update
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PG_PPT; ++j) {
+            sm.u.a[slot_of(tid, j)] = a[j];
+            if (base_i + slot_of(tid, j) < N) ar.anc_out[base_i + slot_of(tid, j)] = a[j];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            const int64_t i = base_i + r * PG_BLK + tid;
+            if (i < N) {
+                // log p(y_{t-1} | aux_{t-1}) of the ancestor: this device's row, or the owning peer's (src/PGAS.py:146)
+                const int an = sm.u.a[r * PG_BLK + tid];
+                const int ra = pr.world > 1 ? an / pr.Nl : 0;
+                lwp[r] = lnv[r] - pr.la[ra][ar.row_prev + (an - (int64_t)ra * pr.Nl)];
+            }
+        }
+        PG_STAMP(5);
+        if (ar.logw_out != nullptr) {
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) {
+                const int64_t i = base_i + r * PG_BLK + tid;
+                if (i < N) ar.logw_out[i] = lwp[r];
+            }
+        }
+        __syncthreads();  // staging area -> ScanSmem reuse
+    }
+    if (ar.mode & PG_RS_SCAN) {
+        double lw[2][PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            const size_t pi = (size_t)base_i + r * PG_BLK + tid;
+            const bool valid_p = pi < (size_t)N;
+            const double l1 = ar.la_t[pi] + lwp[r];
+            lw[0][r] = valid_p ? l1 : -__builtin_inf();
+            lw[1][r] = valid_p ? l1 + ar.h_t[pi] : -__builtin_inf();
+        }
+        PG_STAMP(6);
+        segment_scan<2, false>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segk_w, sb_next.segs_w);
+    }
+    PG_STAMP(7);
+}
+
+// reconstruct_trajectory (src/Filtering.py:40-55) from caller-owned traces and a given final index
+__global__ void k_backtrace_idx(int N, int T, int nx, const double* __restrict__ x_trace, const int32_t* __restrict__ anc_trace,
+                                int64_t idx, double* __restrict__ traj) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t b = idx;
+    for (int i = T - 1; i >= 0; --i) {
+        for (int k = 0; k < nx; ++k) traj[(size_t)i * nx + k] = x_trace[((size_t)i * N + b) * nx + k];
+        if (i > 0) b = anc_trace[(size_t)(i - 1) * N + b];
+    }
+}

@@ -4,13 +4,14 @@ The reference is a single process; this is the build's multi-GPU extension of
 ``condSequentialMonteCarlo.__call__`` (src/PGAS.py:176-228).  Rank r owns particles
 [r N/G, (r+1) N/G); the conditioned particle N-1 lives on the last rank.  Per time step there is ONE
 collective: an all-gather of the per-segment softmax partials (2 x 2 x nseg_local 8-byte words per rank),
-after which every rank evaluates the identical cross-segment scan, so ancestors -- and the sampled
+after which every rank computes the identical group records (k_groups), so ancestors -- and the sampled
 trajectory -- do not depend on the number of ranks.  Ancestors that live on another rank are read
 through xGMI peer mappings of the scan buffers.
 
 Two groups implement the exchange:
   * ``LocalGroup``  -- several shards in ONE process on one device (tests, single-GPU emulation);
-  * ``DistGroup``   -- one shard per process, torch.distributed (backend "nccl" = RCCL) + HIP IPC handles.
+  * ``DistGroup``   -- one shard per process, torch.distributed (backend "nccl" = RCCL) + HIP IPC handles; the time loop
+                       runs inside the library (pgas_shard_sweep).
 """
 from __future__ import annotations
 
@@ -20,7 +21,7 @@ import torch
 from . import random as prng
 from ._lib import Engine
 
-PH_INIT, PH_PROPAGATE, PH_RESAMPLE, PH_UPPER, PH_FINAL_SCAN, PH_FINAL_UPPER, PH_BACKTRACE = range(7)
+PH_INIT, PH_PROPAGATE, PH_STEP, PH_GROUPS, PH_FINAL_SCAN, PH_FINAL, PH_BACKTRACE = range(7)
 
 
 def shard_layout(N_global: int, world: int, seg: int = 1024):
@@ -38,10 +39,10 @@ class _Shard:
         eng.shard_setup(rank, world)
         self.ptrs, (self.nsegp, self.Nl, self.T) = eng.shard_buffers()
         w = 2 * self.nsegp
-        self.segm_w = [eng.dev_tensor(self.ptrs[7 + i], (w,), torch.float64) for i in range(2)]
-        self.segs_w = [eng.dev_tensor(self.ptrs[9 + i], (w,), torch.int64) for i in range(2)]
-        self.segm_g = [eng.dev_tensor(self.ptrs[11 + i], (world * w,), torch.float64) for i in range(2)]
-        self.segs_g = [eng.dev_tensor(self.ptrs[13 + i], (world * w,), torch.int64) for i in range(2)]
+        self.segm_w = [eng.dev_tensor(self.ptrs[9 + i], (w,), torch.float64) for i in range(2)]
+        self.segs_w = [eng.dev_tensor(self.ptrs[11 + i], (w,), torch.int64) for i in range(2)]
+        self.segm_g = [eng.dev_tensor(self.ptrs[13 + i], (world * w,), torch.float64) for i in range(2)]
+        self.segs_g = [eng.dev_tensor(self.ptrs[15 + i], (world * w,), torch.int64) for i in range(2)]
 
 
 class LocalGroup:
@@ -65,13 +66,17 @@ class LocalGroup:
 
 
 class DistGroup:
-    """One shard per process.  torch.distributed carries the all-gather (RCCL for GPU tensors) and, once, the IPC handles."""
+    """One shard per process.  The time loop runs inside the library (pgas_shard_sweep) on every backend:
+      * "nccl": the per-step all-gather is an RCCL call on the sweep's stream (own communicator; torch.distributed only carries
+        the 128-byte id and, once, the IPC handles);
+      * "gloo": the library calls back into `_host_all_gather`, which stages the partials through the host -- the development /
+        test path for several ranks on ONE device, where RCCL refuses duplicate devices.  Same loop, same launches."""
 
     def __init__(self, shard, group=None):
         import torch.distributed as dist
 
         self.dist, self.group, self.shards = dist, group, [shard]
-        self.library_loop = False
+        self.library_loop = True
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         handles = [shard.eng.ipc_export(k) for k in range(7)]
         everyone = [None] * world
@@ -81,26 +86,29 @@ class DistGroup:
                 shard.eng.shard_set_peer(peer, shard.ptrs[:7])
             else:
                 shard.eng.shard_set_peer(peer, [shard.eng.ipc_open(h) for h in hs])
-
-        if dist.get_backend(group) == "nccl":
-            # one process per GPU: the whole time loop runs inside the library, its per-step all-gather as an RCCL call on the
-            # sweep's stream (own communicator: torch.distributed only carries the 128-byte id)
+        self.backend = dist.get_backend(group)
+        if self.backend == "nccl":
             ident = [shard.eng.shard_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ident, src=0, group=group)
             shard.eng.shard_comm_init(ident[0])
-            self.library_loop = True
+        else:
+            shard.eng.shard_set_collective(self._host_all_gather)
 
-    def all_gather(self, parity):
+    def _host_all_gather(self, parity, stream_ptr):
         s = self.shards[0]
-        if self.dist.get_backend(self.group) == "gloo":
-            # development / test path (several ranks on one GPU, where RCCL refuses duplicate devices): stage through the host
+        # the library hands over the raw hipStream_t its loop runs on; NULL (None through ctypes) is the device's default stream
+        st = torch.cuda.ExternalStream(int(stream_ptr), device=s.eng.device) if stream_ptr else torch.cuda.default_stream(s.eng.device)
+        st.synchronize()
+        if parity < 0:   # end-of-sweep barrier: nobody rewrites traces its peers are still chasing ancestors through
+            self.dist.barrier(group=self.group)
+            return 0
+        world = self.dist.get_world_size(self.group)
+        with torch.cuda.stream(st):
             for dst, src in ((s.segm_g[parity], s.segm_w[parity]), (s.segs_g[parity], s.segs_w[parity])):
-                parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(self.dist.get_world_size(self.group))]
+                parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(world)]
                 self.dist.all_gather(parts, src.cpu(), group=self.group)
                 dst.copy_(torch.cat(parts))
-            return
-        self.dist.all_gather_into_tensor(s.segm_g[parity], s.segm_w[parity], group=self.group)
-        self.dist.all_gather_into_tensor(s.segs_g[parity], s.segs_w[parity], group=self.group)
+        return 0
 
     def barrier(self):
         torch.cuda.synchronize()
@@ -118,26 +126,31 @@ def sharded_sweep(group, seed, ref, coeff_mat, error_cov, propagate_chunk=0):
         r = ref if isinstance(ref, torch.Tensor) else torch.as_tensor(np.asarray(ref, dtype=np.float64))
         refs.append(r.to(device=s.eng.device, dtype=torch.float64).reshape(T, s.eng.nx).contiguous())
         trajs.append(torch.empty((T, s.eng.nx), dtype=torch.float64, device=s.eng.device))
-    chunk = propagate_chunk if propagate_chunk > 0 else T
     if getattr(group, "library_loop", False):
-        shards[0].eng.shard_sweep(seed, refs[0], trajs[0], propagate_chunk)   # pgas_shard_sweep: loop + RCCL inside the library
+        shards[0].eng.shard_sweep(seed, refs[0], trajs[0], propagate_chunk)   # pgas_shard_sweep: loop + collective inside the library
         return trajs[0]
+    # several shards in one process: the same phases, interleaved over the shards by hand
+    chunk = propagate_chunk if propagate_chunk > 0 else T
     for s, r in zip(shards, refs):
         s.eng.shard_run(PH_INIT, seed=seed, ref=r)
         for t0 in range(1, T, chunk):
             s.eng.shard_run(PH_PROPAGATE, t0, min(t0 + chunk, T), seed=seed, ref=r)
     for t in range(1, T + 1):
         for s in shards:
-            s.eng.shard_run(PH_RESAMPLE, t, seed=seed)
+            s.eng.shard_run(PH_STEP, t, seed=seed)
         if t < T:
             group.all_gather(t & 1)          # the one collective of the step
             for s in shards:
-                s.eng.shard_run(PH_UPPER, t, seed=seed)
+                s.eng.shard_run(PH_GROUPS, t, seed=seed)
+    if T == 1:
+        for s in shards:
+            X, A, LW, _ = s.eng.traces()
+            LW.zero_()
     for s in shards:
         s.eng.shard_run(PH_FINAL_SCAN, seed=seed)
     group.all_gather(T & 1)
     for s, tr in zip(shards, trajs):
-        s.eng.shard_run(PH_FINAL_UPPER, seed=seed)
+        s.eng.shard_run(PH_FINAL, seed=seed)
         s.eng.shard_run(PH_BACKTRACE, seed=seed, traj=tr)
     group.barrier()                          # peers may still be reading this rank's traces
     return trajs if len(trajs) > 1 else trajs[0]

@@ -153,6 +153,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=20, help="steps of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--chunk", type=int, default=-1, help="time steps per k_propagate launch (engine default if < 0)")
+    ap.add_argument("--force-groups", action="store_true", help="run k_groups between the steps even where k_step could scan the groups itself")
     ap.add_argument("--no-overlap", action="store_true", help="run the weight recursion on the caller's stream (no concurrency)")
     ap.add_argument("--prop-lds", type=int, default=-1, help="LDS bytes reserved per k_propagate workgroup while overlapping (engine default if < 0)")
     ap.add_argument("--workload", choices=["smo", "vehicle", "emps", "smo-alg1"], default="smo",
@@ -200,6 +201,8 @@ def main():
     prof_all = os.environ.get("PGAS_PROF_ALL", "0") == "1"      # profile every timed sweep instead of the last one only
     if args.chunk >= 0:
         eng.set_option(1, args.chunk)      # PGAS_OPT_PROPAGATE_CHUNK
+    if args.force_groups:
+        eng.set_option(2, 1)               # PGAS_OPT_FORCE_SLOW_RESAMPLE
     if args.no_overlap:
         eng.set_option(3, 0)               # PGAS_OPT_OVERLAP
     if args.prop_lds >= 0:

@@ -26,10 +26,17 @@
 #define PGAS_MAX_D 3
 #define PGAS_MAX_J 64 /* distinct frequencies per basis dimension */
 
-/* ---- softmax reference of a segment.  The numerators of a segment are taken relative to a POWER OF TWO:
- * kref = ceil(max_i lw_i * log2 e) (an integer-valued double, -inf for an empty segment), e_i = exp(lw_i - kref ln 2) in (0, 1]
- * with the largest in (1/2, 1], so the 2^51 fixed point keeps at least 51 bits of it.  Across segments the common reference is
- * K = max kref and the rescaling factor 2^(kref - K) is EXACT (one ldexp instead of one exp per segment and workgroup). */
+/* ---- softmax references.  The CDF of a weight vector is built on three levels, each with a
+ * POWER-OF-TWO reference so that every rescaling between levels is exact:
+ *   segment b (PGAS_SEG particles): kref_b = ceil(max_i lw_i * log2 e) (an integer-valued double, -inf for an empty segment),
+ *       e_i = exp(lw_i - kref_b ln 2) in (0, 1] with the largest in (1/2, 1], quantised to 2^-51 and summed as integers;
+ *   group g (PGAS_GRP consecutive segments): KG_g = max kref_b, segment totals rescaled by 2^(kref_b - KG_g);
+ *   top (all groups): K = max KG_g, group totals rescaled by 2^(KG_g - K).
+ * A contribution more than PGAS_LVL_FLUSH binary orders below the reference of the next level is exactly zero: every value
+ * that is kept stays a normal number after both rescalings, which is what makes the hierarchy exact (no transcendental and
+ * no rounding between levels; a workgroup only ever needs the group records plus the segments of the groups it searches). */
+#define PGAS_GRP 64
+#define PGAS_LVL_FLUSH 480.0
 #define PGAS_SEG_LOG2E 0x1.71547652b82fep+0
 #define PGAS_SEG_LN2_HI 0x1.62e42fefa39efp-1
 #define PGAS_SEG_LN2_LO 0x1.abc9e3b39803fp-56
@@ -37,9 +44,11 @@ PGAS_HD double pgas_seg_ref(double m) { return __builtin_ceil(m * PGAS_SEG_LOG2E
 PGAS_HD double pgas_seg_arg(double lw, double kref) {
     return PGAS_FMA(-kref, PGAS_SEG_LN2_LO, PGAS_FMA(-kref, PGAS_SEG_LN2_HI, lw));
 }
-PGAS_HD double pgas_seg_scale(double kref, double K) {
-    const double d = kref - K; /* integer-valued and <= 0, -inf or NaN for empty segments */
-    return (d >= -1100.0) ? ldexp(1.0, (int)d) : 0.0;
+/* 2^(k - K) for a reference k of one level under the reference K >= k of the next; 0 below the flush threshold, for empty
+ * members (k = -inf) and when everything is empty (K = -inf: k - K is NaN) */
+PGAS_HD double pgas_lvl_scale(double k, double K) {
+    const double d = k - K; /* integer-valued and <= 0, -inf or NaN for empty members */
+    return (d >= -PGAS_LVL_FLUSH) ? ldexp(1.0, (int)d) : 0.0;
 }
 
 /* Philox counter layout: (c0, c1, c2, c3) = (particle lo32, particle hi32, time step, stream | draw<<8),

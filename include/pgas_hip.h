@@ -117,7 +117,7 @@ int pgas_get_traces(pgas_ctx* ctx, double** x_trace, int32_t** anc_trace, double
 /* Index drawn by the last sweep at src/PGAS.py:225 (synchronises the stream). */
 int pgas_last_final_index(pgas_ctx* ctx, int64_t* idx, void* stream);
 
-/* Measurement aid (bench.py): when on, pgas_sweep launches its two per-step kernels -- k_resample(_fast) (resampling
+/* Measurement aid (bench.py): when on, pgas_sweep launches its two per-step kernels -- k_step (resampling
  * search + softmax scans) and k_propagate (all particles through a chunk of time steps) -- with start/stop HIP events
  * attached to the dispatch (hipExtLaunchKernelGGL), which carry the kernel's own begin/end timestamps on the stream it
  * runs on.  pgas_get_profile synchronises and returns, for the last sweep, the counts and summed durations of the launches
@@ -127,12 +127,15 @@ int pgas_last_final_index(pgas_ctx* ctx, int64_t* idx, void* stream);
 int pgas_set_profiling(pgas_ctx* ctx, int32_t on);
 int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample_ms, int64_t* propagate_launches,
                      double* propagate_ms, void* stream);
+/* What the last sweep launched: info4 = {time steps per k_propagate launch, 1 if k_step scanned the groups itself (0: k_groups
+ * ran between the steps), padded innermost basis extent JP, particles per basis pass P} -- bench.py labels its kernels from this. */
+int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 
 /* Tuning / test knobs.  PGAS_OPT_PROPAGATE_CHUNK: time steps per k_propagate launch (0 = the whole sweep in one launch). */
 #define PGAS_OPT_PROPAGATE_CHUNK 1
 #define PGAS_OPT_PROPAGATE_LDS 4 /* bytes of LDS reserved per k_propagate workgroup while overlapping (occupancy cap) */
 #define PGAS_OPT_OVERLAP 3 /* 1 (default): weight recursion on an internal stream, concurrent with k_propagate */
-#define PGAS_OPT_FORCE_SLOW_RESAMPLE 2 /* 1: always use the k_resample + k_upper pair (the path taken when N > 2^20 per device) */
+#define PGAS_OPT_FORCE_SLOW_RESAMPLE 2 /* 1: always run k_groups between the steps (the path taken when N > 2^20 per device or sharded) */
 /* 1: CORRECTED mode, not the reference's behaviour.  src/PGAS.py:131-133 propagates every particle from its own previous
  * state (`state`, not `state[a_indices]`) although the ancestors are recorded and used for the weights and the
  * back-trace.  With this option pgas_step / pgas_sweep draw x_t[i] ~ N(A phi(x_{t-1}[a_i]), S) as a particle filter should
@@ -151,28 +154,34 @@ int pgas_reconstruct_trajectory(pgas_ctx* ctx, const double* x_dev, const int32_
 
 /* ---- particle-sharded sweep.  The reference is single-process; these entry points have no
  * counterpart there.  One context per rank holds N_local = N_global / world particles (N_local a multiple of the
- * segment size); the host drives the phases below and performs ONE collective per time step between RESAMPLE(t) and
- * UPPER(t): an all-gather of the segment partials (pgas_shard_buffers: segm_w/segs_w -> segm_g/segs_g, RCCL through
- * torch.distributed).  Ancestors that live on another rank are read through peer mappings (pgas_shard_set_peer;
- * pgas_ipc_export / pgas_ipc_open carry the mappings between processes).  Results do not depend on `world`. */
+ * segment size).  Per time step there is ONE collective between STEP(t) and GROUPS(t): an all-gather of the segment
+ * partials (pgas_shard_buffers: segk_w/segs_w -> segk_g/segs_g); every rank then computes the same group records.
+ * Ancestors that live on another rank are read through peer mappings (pgas_shard_set_peer; pgas_ipc_export / pgas_ipc_open
+ * carry the mappings between processes).  Results do not depend on `world`. */
 #define PGAS_SHARD_INIT 0        /* x_0                      (ref_dev)                         */
 #define PGAS_SHARD_PROPAGATE 1   /* time steps [t, t_aux)    (ref_dev)                         */
-#define PGAS_SHARD_RESAMPLE 2    /* launch t in [1,T]: resample step t-1 (t>1), scan step t (t<T) */
-#define PGAS_SHARD_UPPER 3       /* cross-segment scan of step t + reference ancestor, after the all-gather */
+#define PGAS_SHARD_STEP 2        /* launch t in [1,T]: resample step t-1 (t>1), scan step t (t<T) */
+#define PGAS_SHARD_GROUPS 3      /* group records of step t, after the all-gather               */
 #define PGAS_SHARD_FINAL_SCAN 4  /* softmax scan of logw_{T-1}; all-gather follows              */
-#define PGAS_SHARD_FINAL_UPPER 5 /* final index (src/PGAS.py:224-225)                           */
+#define PGAS_SHARD_FINAL 5       /* group records + final index (src/PGAS.py:224-225)           */
 #define PGAS_SHARD_BACKTRACE 6   /* trajectory (traj_dev), every rank computes the same one     */
 int pgas_shard_setup(pgas_ctx* ctx, int32_t rank, int32_t world);
-int pgas_shard_buffers(pgas_ctx* ctx, void** out15, int64_t* sizes3);
+int pgas_shard_buffers(pgas_ctx* ctx, void** out17, int64_t* sizes3);
 int pgas_shard_set_peer(pgas_ctx* ctx, int32_t peer, const void* const* bufs7);
 int pgas_shard_run(pgas_ctx* ctx, int32_t phase, int32_t t, int32_t t_aux, uint64_t seed, const double* ref_dev, double* traj_dev,
                    void* stream);
 /* The whole sharded sweep inside the library: pgas_shard_unique_id on one rank (128 bytes, to be broadcast by the host),
  * pgas_shard_comm_init on every rank (ncclCommInitRank with the rank / world of pgas_shard_setup), then pgas_shard_sweep runs
  * the phases above with the per-step all-gather issued as an RCCL call on the same stream -- no host round trip per step.
- * RCCL is bound with dlopen at first use (PGAS_E_STATE if it cannot be loaded). */
+ * RCCL is bound with dlopen at first use (PGAS_E_STATE if it cannot be loaded).
+ * pgas_shard_set_collective replaces the RCCL calls of that loop by a host callback (same loop, same launches): it is how
+ * the multi-rank loop is exercised where RCCL is not usable (several ranks sharing one device in the tests).  The callback
+ * gets the scan-buffer parity whose segk_w/segs_w must be gathered into segk_g/segs_g (parity < 0: end-of-sweep barrier)
+ * and the stream the loop runs on; it must leave the gathered arrays visible to work enqueued on that stream afterwards. */
+typedef int (*pgas_allgather_fn)(void* user, int32_t parity, void* stream);
 int pgas_shard_unique_id(void* id128);
 int pgas_shard_comm_init(pgas_ctx* ctx, const void* id128);
+int pgas_shard_set_collective(pgas_ctx* ctx, pgas_allgather_fn fn, void* user);
 int pgas_shard_sweep(pgas_ctx* ctx, uint64_t seed, const double* ref_dev, double* traj_dev, int32_t propagate_chunk, void* stream);
 int pgas_ipc_export(pgas_ctx* ctx, int32_t which, void* handle64);
 int pgas_ipc_open(pgas_ctx* ctx, const void* handle64, void** ptr);

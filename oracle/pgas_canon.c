@@ -271,75 +271,105 @@ static void ks64(double* v) {
     memcpy(v, t, sizeof t);
 }
 
-/* exclusive prefix over n values: three levels of groups of 64, each scanned by ks64 (n <= 64^3) */
-static void ks64_tree_exclusive(const double* x, int n, double* excl) {
-    int n1 = (n + 63) / 64, n2 = (n1 + 63) / 64;
-    double* incA = (double*)calloc((size_t)n1 * 64, sizeof(double));
-    double* incB = (double*)calloc((size_t)n2 * 64, sizeof(double));
-    double incC[64];
-    memset(incC, 0, sizeof incC);
-    memcpy(incA, x, sizeof(double) * n);
-    for (int g = 0; g < n1; ++g) ks64(incA + 64 * g);
-    for (int g = 0; g < n1; ++g) incB[g] = incA[64 * g + 63];
-    for (int h = 0; h < n2; ++h) ks64(incB + 64 * h);
-    for (int h = 0; h < n2 && h < 64; ++h) incC[h] = incB[64 * h + 63];
-    ks64(incC);
-    for (int b = 0; b < n; ++b) {
-        int g = b / 64, h = g / 64;
-        double eC = (h % 64) ? incC[h - 1] : 0.0;
-        double eB = (g % 64) ? incB[g - 1] : 0.0;
-        double eA = (b % 64) ? incA[b - 1] : 0.0;
-        excl[b] = (eC + eB) + eA;
-    }
-    free(incA); free(incB);
-}
-
+/* ---- the hierarchical CDF of DESIGN.md 4.4: segment -> group of PGAS_GRP segments -> top.
+ *   group g:  KG = max kref_b;  t_b = 2^(kref_b - KG) (s_b 2^-51);  e_b = exclusive R16 prefix of t inside the group (64 lanes,
+ *             missing segments are zeros);  w_b = e_b + t_b;  m_b = running maximum of w inside the group;  TG = m of the
+ *             group's last segment
+ *   top:      K = max KG;  TT_g = 2^(KG_g - K) TG_g;  E_g = exclusive prefix of TT (R16 inside blocks of 64 groups, R16 over the
+ *             block totals, E = EC + EB);  W_g = E_g + TT_g;  CM_g = running maximum of W;  S = CM_last
+ *   particle k of segment b of group g:  v_k = max(m_{b-1}, e_b + sc_b (c_k 2^-51)),  num_k = max(CM_{g-1}, E_g + sig_g v_k)
+ * num is non-decreasing in k by construction; every rescaling is by an exact power of two (include/pgas_canon.h). */
 typedef struct {
-    int nseg;
-    double *excl, *scale, *cm;
+    int nseg, n1;
+    double *e, *sc, *m;      /* per segment */
+    double *E, *sig, *CM;    /* per group */
     double S;
     int valid;
 } upper_t;
 
-static void upper_build(upper_t* U, int nseg, const double* segm, const uint64_t* segs) {
+static void upper_build(upper_t* U, int nseg, const double* segk, const uint64_t* segs) {
+    const int n1 = (nseg + PGAS_GRP - 1) / PGAS_GRP, n2 = (n1 + 63) / 64;
     U->nseg = nseg;
-    U->excl = (double*)malloc(sizeof(double) * nseg);
-    U->scale = (double*)malloc(sizeof(double) * nseg);
-    U->cm = (double*)malloc(sizeof(double) * nseg);
-    double* tot = (double*)malloc(sizeof(double) * nseg);
-    double g = -INFINITY;
-    for (int b = 0; b < nseg; ++b)
-        if (segm[b] > g) g = segm[b];
-    for (int b = 0; b < nseg; ++b) {
-        double sc = pgas_seg_scale(segm[b], g);
-        U->scale[b] = sc;
-        tot[b] = sc * (pgas_u64_to_double(segs[b]) * PGAS_FIX_INV);
+    U->n1 = n1;
+    U->e = (double*)malloc(sizeof(double) * nseg);
+    U->sc = (double*)malloc(sizeof(double) * nseg);
+    U->m = (double*)malloc(sizeof(double) * nseg);
+    U->E = (double*)malloc(sizeof(double) * n1);
+    U->sig = (double*)malloc(sizeof(double) * n1);
+    U->CM = (double*)malloc(sizeof(double) * n1);
+    double* KG = (double*)malloc(sizeof(double) * n1);
+    double* TT = (double*)calloc((size_t)n2 * 64, sizeof(double));
+    double K = -INFINITY;
+    for (int g = 0; g < n1; ++g) {
+        const int b0 = g * PGAS_GRP, nb = nseg - b0 < PGAS_GRP ? nseg - b0 : PGAS_GRP;
+        double kg = -INFINITY, t[64], inc[64];
+        for (int l = 0; l < nb; ++l)
+            if (segk[b0 + l] > kg) kg = segk[b0 + l];
+        memset(t, 0, sizeof t);
+        for (int l = 0; l < nb; ++l) {
+            U->sc[b0 + l] = pgas_lvl_scale(segk[b0 + l], kg);
+            t[l] = U->sc[b0 + l] * (pgas_u64_to_double(segs[b0 + l]) * PGAS_FIX_INV);
+        }
+        memcpy(inc, t, sizeof t);
+        ks64(inc);
+        double run = 0.0;
+        for (int l = 0; l < nb; ++l) { /* TG = m of the last REAL segment of the group: padding lanes take no part */
+            const double e = l ? inc[l - 1] : 0.0, w = e + t[l];
+            if (w > run) run = w;
+            U->e[b0 + l] = e;
+            U->m[b0 + l] = run;
+        }
+        KG[g] = kg;
+        TT[g] = run; /* TG for now */
+        if (kg > K) K = kg;
     }
-    ks64_tree_exclusive(tot, nseg, U->excl);
+    for (int g = 0; g < n1; ++g) {
+        U->sig[g] = pgas_lvl_scale(KG[g], K);
+        TT[g] = U->sig[g] * TT[g];
+    }
+    double* incB = (double*)malloc(sizeof(double) * (size_t)n2 * 64);
+    double incC[64];
+    memcpy(incB, TT, sizeof(double) * (size_t)n2 * 64);
+    memset(incC, 0, sizeof incC);
+    for (int h = 0; h < n2; ++h) ks64(incB + 64 * h);
+    for (int h = 0; h < n2 && h < 64; ++h) incC[h] = incB[64 * h + 63];
+    ks64(incC);
     double run = 0.0;
-    for (int b = 0; b < nseg; ++b) {
-        double wend = U->excl[b] + tot[b];
-        if (wend > run) run = wend;
-        U->cm[b] = run;
+    for (int g = 0; g < n1; ++g) {
+        const int h = g / 64;
+        const double eC = h ? incC[h - 1] : 0.0, eB = (g % 64) ? incB[g - 1] : 0.0;
+        U->E[g] = eC + eB;
+        const double W = U->E[g] + TT[g];
+        if (W > run) run = W;
+        U->CM[g] = run;
     }
     U->S = run;
     U->valid = (run > 0.0) && (run < INFINITY);
-    free(tot);
+    free(KG); free(TT); free(incB);
 }
-static void upper_free(upper_t* U) { free(U->excl); free(U->scale); free(U->cm); }
+static void upper_free(upper_t* U) { free(U->e); free(U->sc); free(U->m); free(U->E); free(U->sig); free(U->CM); }
 
-/* #{k : W_k < tau}: the searchsorted(side='left') of src/Filtering.py:34 / src/PGAS.py:122 */
+/* #{k : num_k < tau}: the searchsorted(side='left') of src/Filtering.py:34 / src/PGAS.py:122 */
 static int64_t cdf_count(const upper_t* U, const uint64_t* c, int64_t N, double tau) {
-    int b = 0;
-    while (b < U->nseg && U->cm[b] < tau) ++b;
-    if (b >= U->nseg) return N;
+    int g = 0;
+    while (g < U->n1 && U->CM[g] < tau) ++g;
+    if (g >= U->n1) return N;
+    const double cp = g ? U->CM[g - 1] : 0.0, E = U->E[g], sg = U->sig[g];
+    int b = g * PGAS_GRP;
+    for (;; ++b) { /* the last segment of the group reaches W_g >= tau */
+        double v = E + sg * U->m[b];
+        if (v < cp) v = cp;
+        if (!(v < tau)) break;
+    }
+    const double mp = (b % PGAS_GRP) ? U->m[b - 1] : 0.0;
     int64_t base = (int64_t)b * PGAS_SEG;
     int64_t n = N - base < PGAS_SEG ? N - base : PGAS_SEG;
-    double carry = b ? U->cm[b - 1] : 0.0;
     int64_t cnt = 0;
     for (int64_t k = 0; k < n; ++k) {
-        double num = U->excl[b] + U->scale[b] * (pgas_u64_to_double(c[base + k]) * PGAS_FIX_INV);
-        if (num < carry) num = carry;
+        double v = U->e[b] + U->sc[b] * (pgas_u64_to_double(c[base + k]) * PGAS_FIX_INV);
+        if (v < mp) v = mp;
+        double num = E + sg * v;
+        if (num < cp) num = cp;
         if (num < tau) ++cnt; /* monotone in k, so this is a count of a prefix */
     }
     return base + cnt;
