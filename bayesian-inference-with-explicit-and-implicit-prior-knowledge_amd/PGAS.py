@@ -126,12 +126,17 @@ class PGAS:
         state_trace[0] = torch.as_tensor(np.asarray(init_ref_state, dtype=np.float64), device=dev).reshape(T, nx)
         key, key_para = prng.split(key, 2)                                                # :356
         coeff_mat, error_cov = self.sample_params(key_para, state_trace[0])               # :358
+        # what the chain consumed, iteration by iteration (not in the reference; the parity test replays the chain from it)
+        self.chain_log = dict(step_keys=[None], para_keys=[key_para], params=[(coeff_mat, error_cov)])
         for k in range(1, K):                                                             # :361
             key, key_step = prng.split(key, 2)                                            # :365
             new_state = self.cSMC(key_step, state_trace[k - 1], coeff_mat, error_cov)     # :366-371
             state_trace[k] = new_state.reshape(T, nx)                                     # :374
             key, key_para = prng.split(key, 2)                                            # :377
             coeff_mat, error_cov = self.sample_params(key_para, state_trace[k])           # :378
+            self.chain_log["step_keys"].append(key_step)
+            self.chain_log["para_keys"].append(key_para)
+            self.chain_log["params"].append((coeff_mat, error_cov))
             if progress is not None:
                 progress(k)
         state_trace = state_trace.transpose(0, 1).contiguous()                            # :380 -> (T,K,nx)

@@ -38,7 +38,7 @@ EXPORTS = [
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
-    "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info",
+    "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
     "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
 ]
 
@@ -107,6 +107,10 @@ def load():
     L.pgas_shard_sweep.argtypes = [vp, u64, vp, vp, i32, vp]
     L.pgas_shard_set_collective.restype = C.c_int
     L.pgas_shard_set_collective.argtypes = [vp, ALLGATHER_FN, vp]
+    L.pgas_detmath_eval.restype = C.c_int
+    L.pgas_detmath_eval.argtypes = [i32, i32, vp, vp, vp, i64, vp, vp, vp, vp]
+    L.pgas_shard_probe_collective.restype = C.c_int
+    L.pgas_shard_probe_collective.argtypes = [vp, i32, vp]
     L.pgas_get_launch_info.restype = C.c_int
     L.pgas_get_launch_info.argtypes = [vp, C.POINTER(i32)]
     L.pgas_ipc_export.restype = C.c_int
@@ -140,6 +144,26 @@ def _f64(a):
 
 def _hp(a):
     return a.ctypes.data_as(_dp)
+
+
+def detmath_eval(which, x=None, y=None, words=None, device=None):
+    """Test hook (pgas_detmath_eval): the shared arithmetic primitives evaluated on the device; returns numpy arrays."""
+    L = load()
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else torch.device(device).index or 0)
+    f = lambda a: None if a is None else torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64), device=dev)  # noqa: E731
+    xd, yd = f(x), f(y)
+    wd = None if words is None else torch.as_tensor(np.ascontiguousarray(words, dtype=np.uint32).view(np.int32), device=dev)
+    n = int(xd.numel()) if xd is not None else int(wd.numel() // 6)
+    o0 = torch.empty(n, dtype=torch.float64, device=dev)
+    o1 = torch.empty(n, dtype=torch.float64, device=dev)
+    ow = torch.empty(4 * n, dtype=torch.int32, device=dev)
+    p = lambda t: 0 if t is None else t.data_ptr()  # noqa: E731
+    rc = L.pgas_detmath_eval(dev.index, int(which), p(xd), p(yd), p(wd), n, o0.data_ptr(), o1.data_ptr(), ow.data_ptr(),
+                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise PgasError(f"pgas_detmath_eval failed ({rc})")
+    torch.cuda.synchronize(dev)
+    return o0.cpu().numpy(), o1.cpu().numpy(), ow.cpu().numpy().view(np.uint32).reshape(n, 4)
 
 
 class _DevView:
@@ -383,6 +407,19 @@ class Engine:
 
         self._ag_cb = ALLGATHER_FN(tramp)   # keep the trampoline alive as long as the library may call it
         self._chk(self.lib.pgas_shard_set_collective(self._h, self._ag_cb, None), "pgas_shard_set_collective")
+
+    def shard_probe_collective(self, reps=200):
+        """Mean duration (us) of the step's RCCL all-gather issued `reps` times back to back on an idle stream; None without RCCL."""
+        if getattr(self, "_ag_cb", None) is not None:
+            return None
+        torch.cuda.synchronize(self.device)
+        self._chk(self.lib.pgas_shard_probe_collective(self._h, 3, self._stream()), "pgas_shard_probe_collective")   # warm-up
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._chk(self.lib.pgas_shard_probe_collective(self._h, int(reps), self._stream()), "pgas_shard_probe_collective")
+        e1.record()
+        torch.cuda.synchronize(self.device)
+        return e0.elapsed_time(e1) * 1e3 / reps
 
     def launch_info(self):
         """dict(chunk, local_groups, JP, P) of the last sweep (pgas_get_launch_info)."""

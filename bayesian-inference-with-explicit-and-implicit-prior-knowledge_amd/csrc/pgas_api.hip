@@ -1072,6 +1072,21 @@ int pgas_shard_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* 
     return shard_all_gather(c, -1, st);
 }
 
+/* Measurement aid: `reps` back-to-back issues of the step's all-gather (scan buffer 0) on `stream`, for timing it in isolation.
+ * Only between sweeps (it overwrites the gathered partials of scan buffer 0, which the next sweep rewrites anyway). */
+int pgas_shard_probe_collective(pgas_ctx* c, int32_t reps, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->sharded || !c->comm) FAIL(c, PGAS_E_STATE, "pgas_shard_probe_collective: needs an RCCL communicator (pgas_shard_comm_init)");
+    if (reps < 1) FAIL(c, PGAS_E_ARG, "pgas_shard_probe_collective: reps must be >= 1");
+    DeviceGuard guard(c->device);
+    pgas_allgather_fn keep = c->ag_cb;
+    c->ag_cb = nullptr;
+    int rc = PGAS_OK;
+    for (int i = 0; i < reps && rc == PGAS_OK; ++i) rc = shard_all_gather(c, 0, (hipStream_t)stream);
+    c->ag_cb = keep;
+    return rc;
+}
+
 /* xGMI / IPC plumbing for peers in OTHER processes: export a 64-byte handle of one of this context's buffers
  * (index as in pgas_shard_buffers, 0..6) and map a peer's handle into this process. */
 int pgas_ipc_export(pgas_ctx* c, int32_t which, void* handle64) {
@@ -1093,6 +1108,20 @@ int pgas_ipc_open(pgas_ctx* c, const void* handle64, void** ptr) {
     memcpy(&h, handle64, sizeof h);
     HIPCHK(c, hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));
     return PGAS_OK;
+}
+
+int pgas_detmath_eval(int32_t device, int32_t which, const double* x_dev, const double* y_dev, const uint32_t* w_dev, int64_t n, double* out0_dev,
+                      double* out1_dev, uint32_t* outw_dev, void* stream) {
+    if (which < 0 || which > 7 || n < 0) return PGAS_E_ARG;
+    const bool words = which == 3 || which == 7;
+    if (words ? !w_dev : !x_dev) return PGAS_E_ARG;
+    if ((which == 5 || which == 6) && !y_dev) return PGAS_E_ARG;
+    if (which == 3 ? !outw_dev : !out0_dev) return PGAS_E_ARG;
+    if ((which == 2 || which == 7) && !out1_dev) return PGAS_E_ARG;
+    if (n == 0) return PGAS_OK;
+    DeviceGuard guard(device);
+    hipLaunchKernelGGL(k_detmath, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, which, x_dev, y_dev, w_dev, n, out0_dev, out1_dev, outw_dev);
+    return hipGetLastError() == hipSuccess ? PGAS_OK : PGAS_E_HIP;
 }
 
 int pgas_suffstats(pgas_ctx* c, const double* traj_dev, double* T0_dev, double* T1_dev, double* T2_dev, void* stream) {

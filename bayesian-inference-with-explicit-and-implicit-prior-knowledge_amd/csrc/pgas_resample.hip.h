@@ -816,3 +816,31 @@ __global__ void k_backtrace_idx(int N, int T, int nx, const double* __restrict__
         if (i > 0) b = anc_trace[(size_t)(i - 1) * N + b];
     }
 }
+
+// Test hook: the shared arithmetic primitives of include/pgas_detmath.h / pgas_canon.h evaluated on the device, element by element
+//   which = 0: exp(x)   1: log(x)   2: sin(pi x), cos(pi x)   3: Philox4x32-10 (x = 6 words per element: counter, key -> 4 words)
+//           4: pgas_seg_ref(x)   5: pgas_seg_arg(x, y)   6: pgas_lvl_scale(x, y)   7: standard-normal pair of a Philox block (as 3)
+__global__ void k_detmath(int which, const double* __restrict__ x, const double* __restrict__ y, const uint32_t* __restrict__ w,
+                          int64_t n, double* __restrict__ o0, double* __restrict__ o1, uint32_t* __restrict__ ow) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    switch (which) {
+    case 0: o0[i] = pgas_exp(x[i]); break;
+    case 1: o0[i] = pgas_log(x[i]); break;
+    case 2: pgas_sincospi(x[i], &o0[i], &o1[i]); break;
+    case 3: {
+        const pgas_u32x4 r = pgas_philox4x32_10(w[6 * i], w[6 * i + 1], w[6 * i + 2], w[6 * i + 3], w[6 * i + 4], w[6 * i + 5]);
+        for (int k = 0; k < 4; ++k) ow[4 * i + k] = r.v[k];
+        break;
+    }
+    case 4: o0[i] = pgas_seg_ref(x[i]); break;
+    case 5: o0[i] = pgas_seg_arg(x[i], y[i]); break;
+    case 6: o0[i] = pgas_lvl_scale(x[i], y[i]); break;
+    case 7: {
+        const pgas_u32x4 r = pgas_philox4x32_10(w[6 * i], w[6 * i + 1], w[6 * i + 2], w[6 * i + 3], w[6 * i + 4], w[6 * i + 5]);
+        pgas_normal_pair(r, &o0[i], &o1[i]);
+        break;
+    }
+    default: break;
+    }
+}

@@ -143,6 +143,71 @@ def bench_alg1(args, torch, dist, rank, local_rank, world):
         dist.destroy_process_group()
 
 
+def numpy_baseline_config1(pb, A, S, seed):
+    """BASELINE.md config 1 ("plumbing"): one full conditional-SMC sweep at the reference's own particle count N = 200, T = pb.T,
+    timed with the literal NumPy restatement of the reference (oracle/pgas_numpy.py) and with the canonical C oracle."""
+    from oracle import canon, pgas_numpy
+
+    N, T, nx = 200, pb.T, pb.nx
+    bm, lik = pb.basis_fcn, pb.likelihood_fcn
+    b = bm.basis
+    y = np.asarray(pb.observations, dtype=np.float64).reshape(T, -1)
+    u = np.asarray(pb.inputs, dtype=np.float64).reshape(T, -1)
+    eig = (np.pi * b.indices.astype(np.float64) / b.size) ** 2     # src/BasisFunctions.py:60
+    L = b.size / 2
+
+    def basis(state, ut):
+        state = np.atleast_2d(state)
+        v = state if not np.size(ut) else np.hstack([state, np.broadcast_to(np.atleast_1d(ut), (state.shape[0], np.size(ut)))])
+        xc = v[:, bm.sel] / bm.div - b.center
+        return np.prod(np.sqrt(1 / L) * np.sin(np.sqrt(eig)[None] * (xc[:, None, :] + L)), axis=2)  # :77-80
+
+    def likelihood(obs, state, ut):
+        return pgas_numpy.mvn_logpdf(np.atleast_1d(obs), np.atleast_2d(state) @ lik.H.T, lik.R)
+
+    csmc = pgas_numpy.condSequentialMonteCarlo(N, y, u, pb.init_state_mean, pb.init_state_cov, likelihood, basis)
+    z = np.zeros((T, N, nx))
+    for t in range(1, T):
+        z[t] = canon.normals(seed, canon.STREAM_PROP, t, 0, N, nx)
+    rand = dict(z0=canon.normals(seed, canon.STREAM_INIT, 0, 0, N, nx), z=z,
+                u_resample=np.array([canon.uniform(seed, canon.STREAM_RESAMPLE, t) for t in range(T)]),
+                u_ancestor=np.array([canon.uniform(seed, canon.STREAM_ANCESTOR, t) for t in range(T)]),
+                u_final=canon.uniform(seed, canon.STREAM_FINAL, 0))
+    t0 = time.perf_counter()
+    csmc(rand, pb.X_true, A, S)
+    dt_np = time.perf_counter() - t0
+    cm = canon.CanonModel(N, T, nx, y.shape[1], u.shape[1], b.indices, bm.sel, bm.alpha, bm.beta, b.norm, lik.H, lik.LRinv, lik.cR, y, u)
+    LS, LSinv, cS = cm.chol_parts(S)
+    t0 = time.perf_counter()
+    cm.sweep(seed, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
+    dt_c = time.perf_counter() - t0
+    blas = os.environ.get("OMP_NUM_THREADS", "unset")
+    return {
+        "workload": f"BASELINE.json configs[0]: N={N}, T={T} full sweep incl. traces and back-trace, fp64",
+        "numpy_restatement": {"value": N * (T - 1) / dt_np, "unit": "particle-steps/s", "seconds": dt_np, "cores": 1, "kind": "port",
+                              "note": f"oracle/pgas_numpy.py (literal NumPy restatement of src/PGAS.py:176-228), single process, NumPy {np.__version__}, "
+                                      f"OMP_NUM_THREADS={blas}, host has {os.cpu_count()} logical CPUs (arrays of 200 x 41: no BLAS threading to speak of)"},
+        "c_oracle": {"value": N * (T - 1) / dt_c, "unit": "particle-steps/s", "seconds": dt_c, "cores": 1, "kind": "port",
+                     "note": "oracle/pgas_canon.c, gcc -O2, 1 thread"},
+    }
+
+
+def respawn_under_torchrun(args):
+    """`python bench.py --gpus G` with G > 1 and no launcher: start G ranks (one per GPU) before this process touches the GPU,
+    stream their output and exit with their code.  The driver's own torch.distributed.run launch does not come through here."""
+    import socket
+    import subprocess
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"bench.py: --gpus {args.gpus} without a launcher (WORLD_SIZE unset): starting {args.gpus} ranks with torch.distributed.run", file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,10 +224,14 @@ def main():
     ap.add_argument("--workload", choices=["smo", "vehicle", "emps", "smo-alg1"], default="smo",
                     help="smo = BASELINE configs[1] (the metric's configuration, default); vehicle = configs[2]; emps = configs[4]'s per-GPU chain; "
                          "smo-alg1 = the marginalised online filter (Algorithm1) on the SingleMassOscillator model, one filter step per bench step")
-    ap.add_argument("--mode", choices=["replicas", "sharded"], default="replicas",
-                    help="multi-GPU partition: independent chains, one per GPU (default; BASELINE config 5) or ONE sweep whose "
-                         "--particles x G particles are sharded over the G ranks (RCCL all-gather per step + xGMI peer reads; config 4)")
+    ap.add_argument("--mode", choices=["auto", "replicas", "sharded"], default="auto",
+                    help="multi-GPU partition.  sharded: ONE sweep whose --particles x G particles are sharded over the G ranks (RCCL all-gather of the "
+                         "segment partials per step + xGMI peer reads; BASELINE config 4, the north-star split).  replicas: independent chains, one per GPU "
+                         "(BASELINE config 5).  auto (default): sharded for the smo workload on G > 1 GPUs, replicas for the emps / vehicle / smo-alg1 workloads")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(args)
 
     import torch
     import torch.distributed as dist
@@ -170,12 +239,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # a launcher (torch.distributed.run) with ONE rank and an explicit --mode sharded runs the sharded code path with world = 1:
+    # the same kernels and one-rank RCCL collectives, no wire time -- the figure to hold against the unsharded sweep
+    use_dist = world > 1 or ("WORLD_SIZE" in os.environ and args.mode == "sharded")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -185,31 +257,25 @@ def main():
     if args.workload == "smo-alg1":
         return bench_alg1(args, torch, dist, rank, local_rank, world)
     N, T = args.particles, args.T
-    sharded_mode = args.mode == "sharded" and world > 1
+    mode = args.mode if args.mode != "auto" else ("sharded" if args.workload == "smo" else "replicas")
+    sharded_mode = mode == "sharded" and use_dist
     seed = 12345678 + (0 if sharded_mode else rank)  # independent chains differ by seed (BASELINE config 5 convention: 12345678 + g)
     pb = {"smo": experiments.smo_pgas, "vehicle": experiments.vehicle_pgas, "emps": experiments.emps_pgas}[args.workload](T=T)
     wl_name = {"smo": "SingleMassOscillator PGAS sweep, nx=2, M=41 Hilbert basis (BASELINE.json configs[1])",
                "vehicle": "Vehicle lateral dynamics PGAS sweep, nx=2, ny=2, M=729 3-D Hilbert basis (BASELINE.json configs[2], build's instantiation)",
                "emps": "EMPS PGAS sweep on synthetic data, nx=2, M=729 3-D Hilbert basis (one chain of BASELINE.json configs[4])"}[args.workload]
+    if sharded_mode and args.workload == "smo":
+        wl_name = "SingleMassOscillator PGAS sweep, nx=2, M=41 Hilbert basis, particles sharded over the GPUs (BASELINE.json configs[3] at 8 GPUs)"
     pg = pgas_amd.PGAS(N, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior,
                        pb.basis_fcn, device=f"cuda:{local_rank}")
-    eng = pg.cSMC.engine
-    ref = torch.as_tensor(pb.X_true, device=eng.device)
+    ref = torch.as_tensor(pb.X_true, device=pg.cSMC.engine.device)
     # (A, S) from one sample_params on the initial reference trajectory
     A, S = pg.sample_params(pgas_amd.random.key(seed), ref)
     stride = int(os.environ.get("PGAS_PROF_STRIDE", "1"))       # time every stride-th launch of the profiled sweep(s)
     prof_all = os.environ.get("PGAS_PROF_ALL", "0") == "1"      # profile every timed sweep instead of the last one only
-    if args.chunk >= 0:
-        eng.set_option(1, args.chunk)      # PGAS_OPT_PROPAGATE_CHUNK
-    if args.force_groups:
-        eng.set_option(2, 1)               # PGAS_OPT_FORCE_SLOW_RESAMPLE
-    if args.no_overlap:
-        eng.set_option(3, 0)               # PGAS_OPT_OVERLAP
-    if args.prop_lds >= 0:
-        eng.set_option(4, args.prop_lds)   # PGAS_OPT_PROPAGATE_LDS
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,11 +288,21 @@ def main():
         dist.broadcast(S, src=0)
         grp = sharded.make_dist_group(N * world, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn,
                                       pb.basis_fcn, device=f"cuda:{local_rank}")
-        args.no_profile = True
+        eng = grp.shards[0].eng
+    else:
+        eng = pg.cSMC.engine
+    if args.chunk >= 0:
+        eng.set_option(1, args.chunk)      # PGAS_OPT_PROPAGATE_CHUNK
+    if args.force_groups:
+        eng.set_option(2, 1)               # PGAS_OPT_FORCE_SLOW_RESAMPLE
+    if args.no_overlap:
+        eng.set_option(3, 0)               # PGAS_OPT_OVERLAP
+    if args.prop_lds >= 0:
+        eng.set_option(4, args.prop_lds)   # PGAS_OPT_PROPAGATE_LDS
 
     def one_sweep(sd):
         if grp is not None:
-            sharded.sharded_sweep(grp, sd, ref, A, S, propagate_chunk=64)
+            sharded.sharded_sweep(grp, sd, ref, A, S)
         else:
             pg.cSMC(sd, ref, A, S)
 
@@ -236,7 +312,7 @@ def main():
     t0 = time.perf_counter()
     prof_n, prof_ms, prop_n, prop_ms = 0, 0.0, 0, 0.0
     for k in range(args.steps):
-        # kernel durations: the LAST timed sweep launches every k_resample_fast / k_propagate with start/stop HIP events
+        # kernel durations: the LAST timed sweep launches every k_step / k_propagate with start/stop HIP events
         # (hipExtLaunchKernelGGL: the dispatch's own begin/end timestamps, on the streams the kernels run on).  Timing every
         # launch of every sweep would cost ~8 % of the headline value; one sweep of K gives 2 x (T-1) samples inside the timed region.
         timed_sweep = not args.no_profile and (k == args.steps - 1 or prof_all)
@@ -262,45 +338,84 @@ def main():
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "config": {
-            "workload": f"{wl_name}, N={N} particles/GPU, T={T}, fp64",
-            "particles_per_gpu": N, "T": T,
-            "parallelism": "1 GPU" if world == 1 else (
-                f"one sweep of {N * world} particles sharded over {world} GPUs: RCCL all-gather of segment partials per step + xGMI peer reads"
+            "workload": f"{wl_name}, N={N} particles/GPU" + (f" ({N * world} in all)" if sharded_mode else "") + f", T={T}, fp64",
+            "particles_per_gpu": N, "particles_total": N * world if sharded_mode else N, "T": T,
+            "partition": "particle-sharded" if sharded_mode else ("single GPU" if world == 1 else "replicas"),
+            "parallelism": "1 GPU" if world == 1 and not sharded_mode else (
+                f"one sweep of {N * world} particles sharded over {world} GPUs (one process per GPU): per time step one RCCL all-gather of the "
+                f"segment partials + xGMI peer reads of remote ancestors' rows; per-GPU work is fixed as GPUs are added (weak scaling)"
                 if sharded_mode else
                 f"{world} independent chains, one per GPU, no data-path collective (replicas; --mode sharded runs the particle-sharded sweep)"),
         },
     }
+    if sharded_mode:
+        nsegp = grp.shards[0].nsegp
+        ag_bytes = 2 * 2 * nsegp * 8   # what one rank contributes per step: (kref, total) x two CDFs x padded segments, 8-byte words
+        out["rccl"] = {"rccl_ranks": world, "collectives_per_step": 1, "all_gather_bytes_per_rank_per_step": ag_bytes,
+                       "all_gather_bytes_received_per_rank_per_step": ag_bytes * world}
+        probe_us = eng.shard_probe_collective(200)
+        if probe_us is not None:
+            out["rccl"]["all_gather_us_isolated"] = probe_us
+            out["rccl"]["note"] = ("all_gather_us_isolated = mean duration of the step's all-gather pair issued back to back 200 times on an idle "
+                                   "stream after the timed region (HIP events); inside the sweep it sits on the weight recursion's critical path")
     if rank == 0:
+        info = eng.launch_info()
         if prof_n:
-            # Dominant kernel (largest total duration in profiles/r01_kernel_stats.csv): k_resample_fast, one launch per time step,
-            # N particle-steps per launch -> algorithmic bytes per launch = 52 N.  k_propagate (the other half of every
-            # particle-step: basis, transition, noise) is reported next to it; it covers `chunk` time steps per launch.
+            # The two per-step kernels: k_step (search + weights + scans; N particle-steps per launch) and k_propagate (basis, transition, noise;
+            # N x chunk particle-steps per launch).  The one with the longer time per step is reported as the dominant kernel; algorithmic bytes of a
+            # particle-step = 52, booked in full to it, so `frac` is an upper bound for the pair -- `sweep_frac` is the honest whole-sweep figure.
             us = 1e3 * prof_ms / prof_n
-            achieved = ALG_BYTES_PER_PARTICLE_STEP * N / (us * 1e-6) / 1e9
             p_us = 1e3 * prop_ms / max(prop_n, 1)
-            p_steps = args.chunk if args.chunk > 0 else (1 if args.workload == "smo" else 16)   # time steps per k_propagate launch (engine default: 1 for 2-D bases, 16 for 3-D)
-            traffic, p_traffic = None, None
-            tf = os.path.join(ROOT, "profiles", "traffic_r01.json")
-            if os.path.exists(tf):
-                tj = json.load(open(tf))
-                traffic, p_traffic = tj.get("k_resample_fast_hbm_bytes_per_launch"), tj.get("k_propagate_hbm_bytes_per_step")
+            p_steps = max(info["chunk"], 1)
+            p_us_step = p_us / p_steps
+            kname_step = "k_step<LOCAL>" if info["local_groups"] else "k_step + k_groups"
+            nxv, Dv = pb.nx, len(pb.basis_fcn.sel)
+            kname_prop = f"k_propagate<{nxv},{Dv},{info['JP']},{info['P']}>"
+            per_launch = ALG_BYTES_PER_PARTICLE_STEP * N
+            dom_is_step = us >= p_us_step
+            dom = dict(kernel=kname_step, avg_launch_us=us, launches_timed=prof_n, steps_per_launch=1) if dom_is_step else \
+                dict(kernel=kname_prop, avg_launch_us=p_us, launches_timed=prop_n, steps_per_launch=p_steps)
+            oth = dict(kernel=kname_prop, avg_launch_us=p_us, launches_timed=prop_n, steps_per_launch=p_steps) if dom_is_step else \
+                dict(kernel=kname_step, avg_launch_us=us, launches_timed=prof_n, steps_per_launch=1)
+            achieved = per_launch * dom["steps_per_launch"] / (dom["avg_launch_us"] * 1e-6) / 1e9
+            oth["achieved_GBs"] = per_launch * oth["steps_per_launch"] / (oth["avg_launch_us"] * 1e-6) / 1e9
+            sweep_GBs = ALG_BYTES_PER_PARTICLE_STEP * units / dt / world / 1e9   # per GPU
+            traffic, traffic_src = None, None
+            for tf in ("traffic_r02.json", "traffic_r01.json"):
+                tp = os.path.join(ROOT, "profiles", tf)
+                if os.path.exists(tp):
+                    tj = json.load(open(tp))
+                    key = "k_step_hbm_bytes_per_launch" if dom_is_step else "k_propagate_hbm_bytes_per_step"
+                    if tj.get(key) is not None:
+                        traffic = tj[key] * (1 if dom_is_step else dom["steps_per_launch"])
+                        traffic_src = f"profiles/{tf} ({tj.get('collected', 'date unknown')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, " \
+                                      f"FETCH_SIZE x 2 per the gfx950 correction; a stored measurement, not taken in this run"
+                        oth["traffic_per_step"] = tj.get("k_propagate_hbm_bytes_per_step" if dom_is_step else "k_step_hbm_bytes_per_launch")
+                        if "valu" in tj:
+                            out["valu"] = tj["valu"]
+                        break
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic, "kernel": "k_resample_fast", "avg_launch_us": us, "launches_timed": prof_n,
+                "traffic": traffic, "traffic_source": traffic_src, "kernel": dom["kernel"], "avg_launch_us": dom["avg_launch_us"],
+                "launches_timed": dom["launches_timed"], "steps_per_launch": dom["steps_per_launch"],
                 "launch_sampling": f"every {'launch' if stride == 1 else str(stride) + 'th launch'} of {'every timed sweep' if prof_all else 'the last timed sweep'} "
                                    "carries start/stop HIP events (hipExtLaunchKernelGGL)",
-                "alg_bytes_per_launch": ALG_BYTES_PER_PARTICLE_STEP * N,
+                "alg_bytes_per_launch": per_launch * dom["steps_per_launch"],
+                "sweep_achieved": sweep_GBs, "sweep_frac": sweep_GBs / HBM_PEAK_GBS,
+                "sweep_note": "sweep_* = 52 B x N x (T-1) / wall of the whole sweep per GPU: both kernels, launch gaps, final draw and back-trace included",
                 "hbm_copy_GBs": hbm_copy_rate(torch, eng.device),   # measured attainable rate of a 1 GiB device copy, outside the timed region
-                "second_kernel": {"kernel": "k_propagate<2,2,8,2,2>" if args.workload == "smo" else "k_propagate<2,3,12,2,2>", "avg_launch_us": p_us, "launches_timed": prop_n, "steps_per_launch": p_steps,
-                                  "achieved_GBs": ALG_BYTES_PER_PARTICLE_STEP * N * p_steps / (p_us * 1e-6) / 1e9,
-                                  "traffic_per_step": p_traffic},
-                "note": "the two kernels run concurrently on two streams; both are fp64-VALU-bound (DESIGN.md section 5), "
+                "second_kernel": oth,
+                "note": "the two kernels run concurrently on two streams; both are fp64-VALU-bound (DESIGN.md section 5, profiles/r02_pmc_sq_*.csv), "
                         "so the HBM fraction understates how close they are to their own limit",
             }
         if args.cpu_steps > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(pb, A.cpu().numpy(), S.cpu().numpy(), N, seed, args.cpu_steps)
+            Ah, Sh = A.cpu().numpy(), S.cpu().numpy()
+            out["cpu_baseline"] = cpu_baseline(pb, Ah, Sh, N, seed, args.cpu_steps)
+            if args.workload == "smo":
+                out["cpu_baseline"]["config1"] = numpy_baseline_config1(pb, Ah, Sh, seed)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -183,8 +183,17 @@ int pgas_shard_unique_id(void* id128);
 int pgas_shard_comm_init(pgas_ctx* ctx, const void* id128);
 int pgas_shard_set_collective(pgas_ctx* ctx, pgas_allgather_fn fn, void* user);
 int pgas_shard_sweep(pgas_ctx* ctx, uint64_t seed, const double* ref_dev, double* traj_dev, int32_t propagate_chunk, void* stream);
+/* Measurement aid: issue the step's RCCL all-gather `reps` times on `stream` (between sweeps only). */
+int pgas_shard_probe_collective(pgas_ctx* ctx, int32_t reps, void* stream);
 int pgas_ipc_export(pgas_ctx* ctx, int32_t which, void* handle64);
 int pgas_ipc_open(pgas_ctx* ctx, const void* handle64, void** ptr);
+
+/* Test hook: the arithmetic primitives shared with the CPU oracle (include/pgas_detmath.h, include/pgas_canon.h) evaluated ON THE
+ * DEVICE, element by element, so that the shared header is checked on gfx950 directly and not only through whole-step parity:
+ * which = 0 exp(x), 1 log(x), 2 sin(pi x) -> out0 / cos(pi x) -> out1, 3 Philox4x32-10 (w: 6 words per element = counter[4], key[2];
+ * outw: 4 words), 4 pgas_seg_ref(x), 5 pgas_seg_arg(x, y), 6 pgas_lvl_scale(x, y), 7 the Box-Muller pair of the Philox block of w. */
+int pgas_detmath_eval(int32_t device, int32_t which, const double* x_dev, const double* y_dev, const uint32_t* w_dev, int64_t n,
+                      double* out0_dev, double* out1_dev, uint32_t* outw_dev, void* stream);
 
 /* Sufficient statistics of PGAS.sample_params (src/PGAS.py:294-303, BI:53-61) without the prior:
  * traj_dev (T,nx) -> T0 (M,nx), T1 (M,M) [fp64 MFMA SYRK], T2 (nx,nx); T3 = T-1.

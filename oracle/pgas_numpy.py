@@ -295,3 +295,46 @@ def sample_params(GP_prior, T0, T1, T2, T3, chi2_draws, normals_T, normals_A):
     V_chol = np.linalg.cholesky(col_cov)  # :339
     A = mean + S_chol @ normals_A @ V_chol  # :341 (Q5)
     return A, S, (mean, col_cov, row_scale, df)
+
+
+def pgas_chain(sweep_fcn, basis_fcn, likelihood_fcn, GP_prior, observations, inputs, init_ref_state, K, step_seeds, draws, params=None):
+    """PGAS.__call__, src/PGAS.py:345-397, with explicit randomness.
+
+    sweep_fcn(seed, ref (T,nx), A, S) -> traj (T,nx) stands for condSequentialMonteCarlo.__call__ (:366-371; this module's class
+    with the canonical random numbers, or the canonical C oracle).  step_seeds[k] is the key handed to sweep k (:365),
+    draws[k] = dict(chi2, normals_T, normals_A) the numbers the k-th sample_params consumes (k = 0: :358, k >= 1: :378).
+    basis_fcn(states (n,nx), input) -> (n,M) and likelihood_fcn(obs, states (n,nx), input) -> (n,) are vectorised over rows.
+
+    `params`, if given, is a list of K pairs (A_k, S_k): sweep k+1 then runs with params[k] instead of this restatement's own
+    draw -- teacher forcing, so that two implementations whose sample_params agree to rounding can still be compared sweep
+    by sweep (a sweep is only reproducible bit for bit from identical (A, S)).
+
+    Returns state_trace (T,K,nx) (:380), log_likelihood (T,K) (:383-392) and the restatement's own [(A_k, S_k)].
+    """
+    y = np.asarray(observations, dtype=np.float64)
+    T = y.shape[0]
+    y = y.reshape(T, -1)
+    u = np.asarray(inputs, dtype=np.float64).reshape(T, -1)
+    ref0 = np.asarray(init_ref_state, dtype=np.float64).reshape(T, -1)
+    nx = ref0.shape[1]
+    trace = np.zeros((K, T, nx))                                   # :266-273
+    trace[0] = ref0                                                # :354
+
+    def draw_params(k):
+        traj = trace[k]
+        Phi = np.vstack([basis_fcn(traj[t:t + 1], u[t]) for t in range(T - 1)])   # :294-296 (Q3: traj[:-1] with inputs[:-1])
+        T0, T1, T2, T3 = suff_stats(traj, Phi)                                     # :297-303
+        d = draws[k]
+        A, S, _ = sample_params(GP_prior, T0, T1, T2, T3, d["chi2"], d["normals_T"], d["normals_A"])   # :306-341
+        return A, S
+
+    own = [draw_params(0)]                                         # :358
+    for k in range(1, K):                                          # :361
+        A, S = params[k - 1] if params is not None else own[k - 1]
+        trace[k] = np.asarray(sweep_fcn(step_seeds[k], trace[k - 1], A, S), dtype=np.float64).reshape(T, nx)   # :366-374
+        own.append(draw_params(k))                                 # :378
+    state_trace = np.swapaxes(trace, 0, 1)                         # :380 -> (T,K,nx)
+    ll = np.empty((T, K))
+    for t in range(T):                                             # :383-392
+        ll[t] = likelihood_fcn(y[t], state_trace[t], u[t])
+    return state_trace, ll, own

@@ -99,3 +99,50 @@ def test_vehicle_driver_two_latent_functions():
         assert np.isfinite(res[k]).all(), k
     xm = (res["online_Sigma_X"][:, :, 0] * res["online_weights"]).sum(axis=1)
     assert np.sqrt(np.mean((xm[20:] - res["X"][20:, 0]) ** 2)) < 0.05
+
+
+@pytest.mark.parametrize("name,N,K", [("toy", 700, 4), ("smo", 1500, 4)])
+def test_pgas_chain_against_restated_chain(name, N, K):
+    """PGAS.__call__ (src/PGAS.py:345-397) against oracle/pgas_numpy.pgas_chain on identical randomness: the key splits are
+    recomputed here from the root key, the parameter draws come from the same Philox streams, and every sweep of the restated
+    chain is the canonical C oracle run with the DEVICE's (A_k, S_k) (a sweep is only reproducible bit for bit from identical
+    parameters; the restatement's own draws are compared with the device's at 1e-9).  state_trace must be equal bit for bit."""
+    import torch
+
+    from common import canon_model, experiments, numpy_csmc, pgas_amd
+    from oracle import pgas_numpy as o
+    from pgas_amd import random as prng
+
+    pb = experiments.toy(T=30) if name == "toy" else experiments.smo_pgas(T=25)
+    root = 20241004
+    pg = pgas_amd.PGAS(N, K, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior, pb.basis_fcn)
+    trace, ll = pg(root, pb.X_true)
+    assert tuple(trace.shape) == (pb.T, K, pb.nx) and tuple(ll.shape) == (pb.T, K)
+    # the reference's key handling (:356, :365, :377), recomputed independently of PGAS.__call__'s bookkeeping
+    key, key_para = prng.split(root, 2)
+    para_keys, step_keys = [key_para], [None]
+    for k in range(1, K):
+        key, ks = prng.split(key, 2)
+        key, kp = prng.split(key, 2)
+        step_keys.append(ks)
+        para_keys.append(kp)
+    assert para_keys == pg.chain_log["para_keys"] and step_keys == pg.chain_log["step_keys"]
+    draws = [pg.param_draws(kp) for kp in para_keys]
+    dev_params = [(A.cpu().numpy(), S.cpu().numpy()) for A, S in pg.chain_log["params"]]
+
+    cm = canon_model(pb, N)
+    L0 = np.linalg.cholesky(pb.init_state_cov)
+
+    def sweep(seed, ref, A, S):
+        LS, LSinv, cS = cm.chol_parts(S)
+        return cm.sweep(seed, ref, A, LS, LSinv, cS, pb.init_state_mean, L0)[0]
+
+    nc = numpy_csmc(pb, N)   # literal NumPy callables (basis, likelihood) built from the reference formulas
+    prior = tuple(np.asarray(g, dtype=np.float64) if np.ndim(g) else float(g) for g in pb.GP_prior)
+    st, llo, own = o.pgas_chain(sweep, nc.basis, nc.lik, prior, pb.observations, pb.inputs, pb.X_true, K, step_keys, draws, params=dev_params)
+    assert np.array_equal(trace.cpu().numpy(), st), "state_trace differs from the restated chain"
+    np.testing.assert_allclose(ll.cpu().numpy(), llo, rtol=1e-12, atol=1e-12)
+    for k, ((A, S), (Ao, So)) in enumerate(zip(dev_params, own)):
+        np.testing.assert_allclose(A, Ao, rtol=1e-9, atol=1e-9 * np.abs(Ao).max(), err_msg=f"coeff_mat of iteration {k}")
+        np.testing.assert_allclose(S, So, rtol=1e-9, atol=1e-12, err_msg=f"error_cov of iteration {k}")
+    assert not np.array_equal(st[:, 0], st[:, K - 1]), "the chain must move"

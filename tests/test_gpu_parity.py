@@ -142,32 +142,94 @@ def test_logw_trace_option():
 
 
 def test_full_size_properties():
-    """BASELINE size N = 2^20 (T shortened): size-independent properties + oracle check of step 1."""
-    pb = experiments.smo_pgas(T=6)
+    """BASELINE size N = 2^20 (T shortened to 18): size-independent properties of the whole sweep, and EVERY one of its 17 steps checked
+    bit for bit against the canonical C oracle (teacher-forced with the device's own previous states and log-weights, which are
+    themselves checked one step earlier): this is the k_step path of the bench -- 1024 segments, 16 groups, staged windows -- at full size."""
+    T = 18
+    pb = experiments.smo_pgas(T=T)
     N = 1 << 20
     A, S = experiments.initial_params(pb)
     csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
-                                             pb.likelihood_fcn, pb.basis_fcn)
+                                             pb.likelihood_fcn, pb.basis_fcn, keep_logw_trace=True)
     traj = csmc(SEED, pb.X_true, A, S)
-    X, ANC, LW, _ = csmc.engine.traces()
+    assert csmc.engine.launch_info()["local_groups"], "N = 2^20 on one device must take the k_step<LOCAL> path the bench measures"
+    X, ANC, LW, LT = csmc.engine.traces()
     a = ANC[: pb.T - 1]
     assert int(a.min()) >= 0 and int(a.max()) < N
     assert bool((a[:, 1:-1] >= a[:, :-2]).all()), "resampled indices must be sorted"
     assert torch.equal(X[:, -1, :], torch.as_tensor(pb.X_true, device=X.device)), "conditioned particle must follow the reference"
     assert bool(torch.isfinite(LW).all())
-    # offspring counts of systematic resampling are within +-1 of N w (SURVEY 8c-1), checked through the oracle on step 1
     cm = canon_model(pb, N)
     LS, LSinv, cS = cm.chol_parts(S)
     x0 = cm.init_state(SEED, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov), pb.X_true[0])
-    lwo, xo, ao, dbg = cm.step(1, SEED, x0, None, A, LS, LSinv, cS, pb.X_true[1], debug=True)
-    _eq(X[1], xo, "x_trace[1] at N=2^20")
-    _eq(ANC[0], ao, "anc_trace[0] at N=2^20")
-    w = np.exp(dbg["lw1"] - dbg["lw1"].max())
-    w /= w.sum()
-    counts = np.bincount(ao[:-1], minlength=N)
-    counts[ao[-1]] += 0  # the conditioned slot is drawn separately (src/PGAS.py:127)
-    assert np.all(np.abs(counts - N * w) <= 2.0)
+    _eq(X[0], x0, "x_trace[0] at N=2^20")
+    for t in range(1, T):
+        xp = X[t - 1].cpu().numpy()
+        lwp = None if t == 1 else LT[t - 1].cpu().numpy()
+        lwo, xo, ao, dbg = cm.step(t, SEED, xp, lwp, A, LS, LSinv, cS, pb.X_true[t], debug=True)
+        _eq(X[t], xo, f"x_trace[{t}] at N=2^20")
+        _eq(ANC[t - 1], ao, f"anc_trace[{t - 1}] at N=2^20")
+        _eq(LT[t], lwo, f"log_weights_trace[{t}] at N=2^20")
+        if t in (1, T - 1):
+            # offspring counts of systematic resampling are within +-1 of N w (SURVEY 8c-1)
+            w = np.exp(dbg["lw1"] - dbg["lw1"].max())
+            w /= w.sum()
+            counts = np.bincount(ao[:-1], minlength=N)
+            assert np.all(np.abs(counts - N * w) <= 2.0)
     assert traj.shape == (pb.T, 2)
+    b = csmc.engine.last_final_index()
+    Xn, An = X.cpu().numpy(), ANC.cpu().numpy()
+    for t in range(pb.T - 1, -1, -1):
+        assert np.array_equal(Xn[t, b], traj[t].cpu().numpy())
+        if t:
+            b = An[t - 1, b]
+
+
+@pytest.mark.parametrize("name", ["emps", "veh"])
+def test_full_size_properties_m729(name):
+    """BASELINE configs[2] / configs[4] at their full size (N = 2^20, M = 729, 3-D basis; T shortened): size-independent properties
+    of the sweep and the first two steps against the canonical oracle bit for bit."""
+    T = 4
+    pb = experiments.emps_pgas(T=T) if name == "emps" else experiments.vehicle_pgas(T=T)
+    N = 1 << 20
+    A, S = experiments.initial_params(pb)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn, keep_logw_trace=True)
+    traj = csmc(SEED, pb.X_true, A, S)
+    X, ANC, LW, LT = csmc.engine.traces()
+    a = ANC[: T - 1]
+    assert int(a.min()) >= 0 and int(a.max()) < N
+    assert bool((a[:, 1:-1] >= a[:, :-2]).all()), "resampled indices must be sorted"
+    assert torch.equal(X[:, -1, :], torch.as_tensor(pb.X_true, device=X.device)), "conditioned particle must follow the reference"
+    assert bool(torch.isfinite(LW).all()) and traj.shape == (T, 2)
+    cm = canon_model(pb, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    for t in (1, 2):
+        lwo, xo, ao = cm.step(t, SEED, X[t - 1].cpu().numpy(), None if t == 1 else LT[t - 1].cpu().numpy(), A, LS, LSinv, cS, pb.X_true[t])
+        _eq(X[t], xo, f"{name}: x_trace[{t}] at N=2^20")
+        _eq(ANC[t - 1], ao, f"{name}: anc_trace[{t - 1}] at N=2^20")
+        _eq(LT[t], lwo, f"{name}: log_weights_trace[{t}] at N=2^20")
+
+
+def test_two_million_particles_group_path():
+    """N = 2^21 on one device (2048 segments, 32 groups): beyond the window of k_step<LOCAL>, the sweep runs k_groups between the
+    steps -- the path every rank of a sharded sweep takes.  Three steps against the oracle, bit for bit."""
+    T = 4
+    pb = experiments.smo_pgas(T=T)
+    N = 1 << 21
+    A, S = experiments.initial_params(pb)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn, keep_logw_trace=True)
+    csmc(SEED, pb.X_true, A, S)
+    assert not csmc.engine.launch_info()["local_groups"]
+    X, ANC, LW, LT = csmc.engine.traces()
+    cm = canon_model(pb, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    for t in (1, 2, 3):
+        lwo, xo, ao = cm.step(t, SEED, X[t - 1].cpu().numpy(), None if t == 1 else LT[t - 1].cpu().numpy(), A, LS, LSinv, cS, pb.X_true[t])
+        _eq(X[t], xo, f"x_trace[{t}] at N=2^21")
+        _eq(ANC[t - 1], ao, f"anc_trace[{t - 1}] at N=2^21")
+        _eq(LT[t], lwo, f"log_weights_trace[{t}] at N=2^21")
 
 
 def test_error_reporting():

@@ -155,3 +155,30 @@ def test_corrected_mode_matches_numpy(name, N):
     cm.set_corrected(True)
     _, xk, ak = cm.step(5, SEED, x, lw, A, LS, LSinv, cS, pb.X_true[5])
     assert np.array_equal(ad, ak) and not np.array_equal(xd, xk)
+
+
+@pytest.mark.parametrize("nseg,spread", [(70, 0.0), (200, 40.0), (4200, 3.0), (4200, 300.0)])
+def test_hierarchical_cdf_against_exact_arithmetic(nseg, spread):
+    """The three-level CDF of DESIGN.md 4.4 (segment -> group of 64 -> blocks of 64 groups) on synthetic log-weights with very different
+    scales from segment to segment (groups and blocks get different power-of-two references): resampled indices must equal
+    searchsorted on an exactly summed softmax away from ties, for 1, 2 and 66 groups (the last one exercises the second top-level block)."""
+    rng = np.random.default_rng(nseg)
+    N = nseg * 1024 - 300
+    base = np.repeat(rng.uniform(-spread, 0.0, nseg), 1024)[:N]
+    lw = base + rng.uniform(-3.0, 0.0, N)
+    segm, segs, c = canon.segment_partials(lw)
+    u = 0.37
+    w = np.exp(np.longdouble(lw) - np.longdouble(lw.max()))
+    W = np.cumsum(w)
+    W = np.float64(W / W[-1])
+    U = (u + np.arange(N)) / N
+    expect_all = np.minimum(np.searchsorted(W, U, side="left"), N - 1)
+    for i0, i1 in ((0, 4096), (N // 2 - 1000, N // 2 + 3096), (N - 4096, N)):
+        got = canon.resample_range(segm, segs, c, N, u, i0, i1)
+        exp = expect_all[i0:i1]
+        bad = np.nonzero(got != exp)[0]
+        for k in bad:   # a differing index must be explained by U lying within rounding of a CDF value
+            lo, hi = sorted((int(got[k]), int(exp[k])))
+            assert np.all(np.abs(W[lo:hi] - U[i0 + k]) < 1e-9), (nseg, spread, i0 + k, got[k], exp[k])
+        assert len(bad) <= 0.01 * len(got)
+        assert np.all(np.diff(got) >= 0)

@@ -143,3 +143,47 @@ def test_conditional_smc_invariants():
     assert np.allclose(lw, nm.lik(nm.y[1], xn, nm.u[1]) - ll_aux[a])
     w_anc = o.softmax(ll_aux + o.mvn_logpdf(pb.X_true[1], aux, S))
     assert a[-1] == min(np.searchsorted(np.cumsum(w_anc), rand["u_ancestor"][1]), N - 1)
+
+
+def test_pgas_chain_restatement_structure():
+    """oracle/pgas_numpy.pgas_chain (src/PGAS.py:345-397): with a sweep that returns a known function of its inputs, the
+    restated chain must thread the trajectories, the parameters and the draws exactly as the reference loop does:
+    trace[0] = init_ref, sweep k sees trace[k-1] and the parameters drawn from trace[k-1], the likelihood block is evaluated on the
+    swapped (T,K,nx) trace, and `params` teacher-forces the sweeps without changing the restatement's own draws."""
+    from oracle import pgas_numpy as o
+
+    rng = np.random.default_rng(0)
+    T, nx, M, K = 9, 1, 4, 4
+    y = rng.standard_normal(T)
+    u = np.zeros(T)
+    ref = rng.standard_normal((T, nx))
+    basis = lambda x, ut: np.cos(np.arange(1, M + 1)[None] * np.atleast_2d(x)[:, :1])   # noqa: E731
+    lik = lambda obs, x, ut: -0.5 * (obs[0] - np.atleast_2d(x)[:, 0]) ** 2               # noqa: E731
+    prior = o.prior_mniw_2naturalPara(np.zeros((nx, M)), np.eye(M), np.eye(nx), 3.0)
+    draws = [dict(chi2=rng.chisquare(5, nx), normals_T=rng.standard_normal((nx, nx)), normals_A=rng.standard_normal((nx, M))) for _ in range(K)]
+    calls = []
+
+    def sweep(seed, refk, A, S):
+        calls.append((seed, refk.copy(), A.copy(), S.copy()))
+        return refk + 0.1 * seed + A.sum()
+
+    seeds = [None, 1, 2, 3]
+    st, ll, own = o.pgas_chain(sweep, basis, lik, prior, y, u, ref, K, seeds, draws)
+    assert st.shape == (T, K, nx) and ll.shape == (T, K) and len(own) == K and len(calls) == K - 1
+    assert np.array_equal(st[:, 0], ref)
+    for k in range(1, K):
+        seed, refk, A, S = calls[k - 1]
+        assert seed == seeds[k] and np.array_equal(refk, st[:, k - 1]) and np.array_equal(A, own[k - 1][0]) and np.array_equal(S, own[k - 1][1])
+        assert np.array_equal(st[:, k], refk + 0.1 * seed + A.sum())
+    # parameters of iteration k are the sample_params of trajectory k with draws[k]
+    for k in range(K):
+        Phi = np.vstack([basis(st[t:t + 1, k], u[t]) for t in range(T - 1)])
+        A, S, _ = o.sample_params(prior, *o.suff_stats(st[:, k], Phi), draws[k]["chi2"], draws[k]["normals_T"], draws[k]["normals_A"])
+        assert np.array_equal(A, own[k][0]) and np.array_equal(S, own[k][1])
+    assert np.allclose(ll, -0.5 * (y[:, None] - st[:, :, 0]) ** 2)
+    # teacher forcing: the sweeps see the forced parameters, the restatement's own draws still follow its trajectories
+    forced = [(np.full((nx, M), 0.5), np.eye(nx)) for _ in range(K)]
+    calls.clear()
+    st2, _, own2 = o.pgas_chain(sweep, basis, lik, prior, y, u, ref, K, seeds, draws, params=forced)
+    assert all(np.array_equal(c[2], forced[0][0]) for c in calls)
+    assert np.array_equal(own2[0][0], own[0][0]) and not np.array_equal(st2[:, 1], st[:, 1])
