@@ -810,6 +810,11 @@ int pgas_get_launch_info(pgas_ctx* c, int32_t* info4) {
     return PGAS_OK;
 }
 
+#ifdef PG_DEBUG_DUMP
+int pgas_debug_dump(double* out /* 4*64 */) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(double) * 4 * 64) == hipSuccess ? 0 : -2;
+}
+#endif
 #ifdef PG_STAMPS
 int pgas_debug_stamps(unsigned long long* out /* 2048*16 */) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 2048 * 16) == hipSuccess ? 0 : -2;

@@ -484,6 +484,42 @@ __global__ __launch_bounds__(PG_BLK) void k_init(DevModel md, uint64_t seed, con
 // lw[r] is the log-weight of particle seg*SEG + r*BLK + tid (-inf when past N).  Writes the
 // quantised inclusive cumsum (index order) and the segment (max, total).
 // ------------------------------------------------------------------------------------------
+// q = rint(exp(x) 2^51) as an integer, for x <= 0.25: the softmax numerators of DESIGN.md 4.3 (x = lw - kref ln 2 <= 0 up to rounding).
+// Same values as pgas_double_to_u64(rint(pgas_exp(x) * 2^51)) with "0 unless exp(x) > 0" (include/pgas_detmath.h) on that domain, in
+// fewer instructions: the argument is clamped at -708 instead of selected afterwards (exp(-708) 2^51 = 7e-293 rounds to 0, as the
+// flushed 0 does; NaN and -inf take the same way), the factor 2^51 rides in the exponent that scales the polynomial, and the
+// round-to-nearest-even integer is read from the mantissa of v + 2^52 (0 <= v < 2^52: exact, same rounding as rint).
+template <int NB>
+__device__ __forceinline__ void dev_exp_q51_n(const double (&x)[NB], uint64_t (&q)[NB]) {
+    const double LOG2E = 0x1.71547652b82fep+0;
+    const double LN2_HI = 0x1.62e42fefa39efp-1;
+    const double LN2_LO = 0x1.abc9e3b39803fp-56;
+    const double C[13] = {0x1.1eed8eff8d898p-29, 0x1.ae64567f544e4p-26, 0x1.27e4fb7789f5cp-22, 0x1.71de3a556c734p-19,
+                          0x1.a01a01a01a01ap-16, 0x1.a01a01a01a01ap-13, 0x1.6c16c16c16c17p-10, 0x1.1111111111111p-7,
+                          0x1.5555555555555p-5,  0x1.5555555555555p-3,  0.5, 1.0, 1.0};
+    double k[NB], r[NB], p[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const double xc = __builtin_fmax(x[i], -708.0);   // NaN -> -708 as well (fmax ignores NaN): q = 0 like the reference expression
+        k[i] = __builtin_rint(xc * LOG2E);
+        r[i] = PGAS_FMA(-k[i], LN2_HI, xc);
+        r[i] = PGAS_FMA(-k[i], LN2_LO, r[i]);
+        p[i] = 0x1.6124613a86d09p-33; /* 1/13! */
+    }
+#pragma unroll
+    for (int j = 0; j < 13; ++j)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) p[i] = PGAS_FMA(p[i], r[i], C[j]);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        // p in (0.70, 1.42), k in [-1022, 0]: v = p 2^(k + 51) is a normal number below 2^52
+        const int ki = (int)k[i] + PGAS_FIX_BITS;
+        const double v = __hiloint2double(__double2hiint(p[i]) + (int)((unsigned)ki << 20), __double2loint(p[i]));
+        const double y = v + 0x1p52;
+        q[i] = ((uint64_t)(uint32_t)(__double2hiint(y) & 0x000fffff) << 32) | (uint32_t)__double2loint(y);
+    }
+}
+
 struct ScanSmem {
     uint64_t q[2][PGAS_SEG];
     double red[2][PG_BLK / 64];
@@ -508,27 +544,24 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
     __syncthreads();
     uint64_t qsum_b = 0;
     {
-        double arg[NW * PG_PPT], ev[NW * PG_PPT];
 #pragma unroll
-        for (int w = 0; w < NW; ++w) {
+        for (int w = 0; w < NW; ++w) {   // one batch of four numerators per weight vector: half the live registers of one batch of eight
             double m = sm.red[w][0];
 #pragma unroll
             for (int v = 1; v < PG_BLK / 64; ++v) m = __builtin_fmax(m, sm.red[w][v]);
             const double kref = pgas_seg_ref(m);  // power-of-two reference of the segment (include/pgas_canon.h)
             mx[w] = kref;
+            double arg[PG_PPT];
+            uint64_t qv[PG_PPT];
 #pragma unroll
-            for (int r = 0; r < PG_PPT; ++r) arg[w * PG_PPT + r] = pgas_seg_arg(lw[w][r], kref);
-        }
-        pgas_exp_n(arg, ev, NW * PG_PPT);
-#pragma unroll
-        for (int w = 0; w < NW; ++w)
+            for (int r = 0; r < PG_PPT; ++r) arg[r] = pgas_seg_arg(lw[w][r], kref);
+            dev_exp_q51_n<PG_PPT>(arg, qv);
 #pragma unroll
             for (int r = 0; r < PG_PPT; ++r) {
-                const double e = ev[w * PG_PPT + r];
-                const uint64_t q = (e > 0.0) ? pgas_double_to_u64(__builtin_rint(e * PGAS_FIX_SCALE)) : 0ull;
-                if (w == 0 || STORE_B) sm.q[w][r * PG_BLK + tid] = q;  // strided -> contiguous particle order for the prefix
-                else qsum_b += q;                                      // only the segment total is wanted: any order will do
+                if (w == 0 || STORE_B) sm.q[w][r * PG_BLK + tid] = qv[r];  // strided -> contiguous particle order for the prefix
+                else qsum_b += qv[r];                                      // only the segment total is wanted: any order will do
             }
+        }
     }
     __syncthreads();
     uint64_t loc[NW][PG_PPT], incl[NW];

@@ -23,7 +23,15 @@
 #define PG_FSTAGE 2                          // source segments staged at once (LDS budget: five workgroups per CU)
 #define PG_NCAND 8                           // staged candidates per workgroup before falling back to per-slot bisection
 #define PG_DEXP_ZERO (-32768)
+#ifdef PG_COLD_NOINLINE
+#define PG_COLD_ATTR __noinline__
+#else
+#define PG_COLD_ATTR __forceinline__
+#endif
 static_assert(PG_MAX_GRP <= 128, "top_scan_wave handles two blocks of 64 groups");
+#ifdef PG_DEBUG_DUMP
+__device__ double g_dbg[4][64];
+#endif
 
 // (rank, cdf, local segment) -> word of the gathered partial arrays
 __device__ __forceinline__ size_t partial_at(const ScanBufs& sb, int cdf, int b) {
@@ -279,9 +287,23 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
     }
 }
 
-// branch-free lower bound over the +inf padded window: #{wb : cm[wb] < tau}
+// #{wb : cm[wb] < tau} over the +inf padded window, by every wave for itself: one ballot over the group ends, one over the
+// segments of the group found (two dependent LDS reads instead of ten)
 template <class SM>
 __device__ __forceinline__ int win_lower_bound(const SM& sm, double tau) {
+    // branch-free on purpose: a build with an early `return PG_WIN_SEG` between the two ballots produced wrong ancestors in k_back /
+    // k_step for some workgroups although each part was right on its own (and a barrier anywhere nearby hid it); see DESIGN.md 8
+    const int lane = threadIdx.x & 63;
+    const double ge = sm.cm[((lane & (PG_WIN_GRP - 1)) << 6) + 63];
+    const int gw = __popcll(__ballot(lane < PG_WIN_GRP && ge < tau));
+    const int g0 = __builtin_amdgcn_readfirstlane(gw < PG_WIN_GRP ? gw : PG_WIN_GRP - 1) << 6;
+    const int inner = __popcll(__ballot(sm.cm[g0 + lane] < tau));
+    return gw >= PG_WIN_GRP ? PG_WIN_SEG : g0 + inner;
+}
+
+// the same count for a threshold that differs from lane to lane (degenerate path): branch-free bisection
+template <class SM>
+__device__ __forceinline__ int win_lower_bound_lane(const SM& sm, double tau) {
     int p = 0;
 #pragma unroll
     for (int step = PG_WIN_SEG / 2; step >= 1; step >>= 1)
@@ -393,26 +415,32 @@ __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOC
         const double tau_first = U_first * S, tau_last = U_last * S;
         int b_lo = win_lower_bound(sm, tau_first), b_hi = win_lower_bound(sm, tau_last);
         if (b_hi > nwin - 1) b_hi = nwin - 1;   // slots beyond the last segment keep a = N-1
-        // enumerate the non-empty source segments of [b_lo, b_hi] (a segment whose running max did not move owns no slot)
-        // by bisection jumps: the next one after carry c is #{b : cm[b] <= c}.  Bounded work however long the run of
-        // empty segments between two heavy particles is.
-        int b = b_lo;
-        while (ns <= PG_NCAND) {
-            const double c0 = b ? sm.cm[b - 1] : (win_b0 ? sm.gCP[0] : 0.0);
-            int nb = 0;
-#pragma unroll
-            for (int step = PG_WIN_SEG / 2; step >= 1; step >>= 1)
-                if (sm.cm[nb + step - 1] <= c0) nb += step;
-            if (nb + 1 <= PG_WIN_SEG && sm.cm[nb] <= c0) ++nb;
-            if (nb > b_hi) break;
-            if (ns < PG_NCAND && tid == 0) {
-                sm.cand_b[ns] = win_b0 + nb;
-                sm.cand_cy[ns] = c0;
-                sm.cand_p[ns] = win_params(sm, nb);
+        // enumerate the non-empty source segments of [b_lo, b_hi] (a segment whose running max did not move owns no slot):
+        // per window group one ballot of "the running maximum moved here"; the lane that owns a candidate writes its record.
+        // Bounded work however long the run of empty segments between two heavy particles is.
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int gw = b_lo >> 6; gw <= (b_hi >> 6) && ns <= PG_NCAND; ++gw) {   // uniform
+            const int wb = (gw << 6) + lane;
+            const double v = sm.cm[wb];
+            const double vp = wb ? sm.cm[wb > 0 ? wb - 1 : 0] : (win_b0 ? sm.gCP[0] : 0.0);
+            const bool cand = wb >= b_lo && wb <= b_hi && v > vp;
+            const unsigned long long mask = __ballot(cand);
+            const int rank = ns + __popcll(mask & ((1ull << lane) - 1ull));
+            if (wave == 0 && cand && rank < PG_NCAND) {
+                sm.cand_b[rank] = win_b0 + wb;
+                sm.cand_cy[rank] = vp;
+                sm.cand_p[rank] = win_params(sm, wb);
             }
-            ++ns;
-            b = nb + 1;
+            ns += __popcll(mask);
         }
+        if (ns > PG_NCAND + 1) ns = PG_NCAND + 1;
+#ifdef PG_DEBUG_DUMP
+        if (seg == PG_DEBUG_DUMP && lane == 0) {
+            double* d = g_dbg[wave];
+            d[0] = S; d[1] = b_lo; d[2] = b_hi; d[3] = ns; d[4] = tau_first; d[5] = tau_last; d[6] = win_b0; d[7] = nwin;
+            for (int k = 0; k < 24; ++k) d[8 + k] = sm.cm[k];
+        }
+#endif
     }
     PG_STAMP(2);
     if (valid && covered && ns > 0 && ns <= PG_NCAND) {
@@ -458,14 +486,13 @@ __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOC
             PG_STAMP(3);
             const double* __restrict__ num = &sm.u.num[0][0];
             int pos[PG_PPT] = {0, 0, 0, 0};
+            static_assert((PG_FSTAGE * PGAS_SEG & (PG_FSTAGE * PGAS_SEG - 1)) == 0, "power-of-two window: pos + step - 1 never leaves it");
 #pragma unroll
             for (int step = PG_FSTAGE * PGAS_SEG / 2; step >= 1; step >>= 1) {
 #pragma unroll
                 for (int j = 0; j < PG_PPT; ++j) {  // loads are unconditional so the four chains advance in lock step
-                    const int q = pos[j] + step;
-                    const int qc = q <= PG_FSTAGE * PGAS_SEG ? q : PG_FSTAGE * PGAS_SEG;
-                    const double v = num[qc - 1];
-                    pos[j] = (q <= PG_FSTAGE * PGAS_SEG && v < tau[j]) ? q : pos[j];
+                    const double v = num[pos[j] + step - 1];
+                    pos[j] = (v < tau[j]) ? pos[j] + step : pos[j];
                 }
             }
 #pragma unroll
@@ -481,7 +508,7 @@ __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOC
         // degenerate weights: per-slot bisection, segment level in LDS, particle level in global memory
 #pragma unroll
         for (int j = 0; j < PG_PPT; ++j) {
-            const int wb = win_lower_bound(sm, tau[j]);
+            const int wb = win_lower_bound_lane(sm, tau[j]);
             if (wb < nwin) {
                 const SegParams p = win_params(sm, wb);
                 const int b = win_b0 + wb;
@@ -713,6 +740,13 @@ struct StepArgs {
     double* logw_out;        // optional (N) logw_{t-1}
 };
 
+// Out-of-line copy for the path that practically never runs (the hand-off word of the ancestor workgroup did not arrive within
+// the spin budget): keeps the second instance of the count out of k_step's instruction stream.
+template <bool LOCAL>
+__device__ PG_COLD_ATTR int cdf_count_wg_cold(WinSmemT<LOCAL>& sm, const ScanBufs& sb, const Peers& pr, int nseg, int N, double U, const AncIn& in) {
+    return cdf_count_wg<LOCAL>(sm, sb, pr, 1, nseg, N, U, nullptr, nullptr, &in);
+}
+
 template <bool LOCAL>
 __global__ __launch_bounds__(PG_BLK, 5) void k_step(DevModel md, StepArgs ar, ScanBufs sb_prev, ScanBufs sb_next, Peers pr) {
     __shared__ WinSmemT<LOCAL> sm;
@@ -755,7 +789,7 @@ __global__ __launch_bounds__(PG_BLK, 5) void k_step(DevModel md, StepArgs ar, Sc
             int ref_idx = sm.cnt[1];
             if (ref_idx < 0) {  // uniform: the word never arrived -- draw the ancestor here
                 __syncthreads();
-                ref_idx = cdf_count_wg<LOCAL>(sm, sb_prev, pr, 1, md.nseg_g, md.Ng, ar.u2_prev, nullptr, nullptr, &ar.anc_in);
+                ref_idx = cdf_count_wg_cold<LOCAL>(sm, sb_prev, pr, md.nseg_g, md.Ng, ar.u2_prev, ar.anc_in);
             }
 #pragma unroll
             for (int j = 0; j < PG_PPT; ++j)
