@@ -28,7 +28,7 @@ class _ModelDesc(C.Structure):
         ("idx", _ip), ("sel", _ip), ("alpha", _dp), ("beta", _dp), ("nrm", C.c_double),
         ("H", _dp), ("LRinv", _dp), ("cR", C.c_double),
         ("m0", _dp), ("L0", _dp), ("y", _dp), ("u", _dp),
-        ("device", C.c_int32), ("keep_logw_trace", C.c_int32),
+        ("device", C.c_int32), ("keep_logw_trace", C.c_int32), ("no_fast_variant", C.c_int32),
     ]
 
 
@@ -203,6 +203,7 @@ class Engine:
             k["idx"].ctypes.data_as(_ip), k["sel"].ctypes.data_as(_ip), _hp(k["alpha"]), _hp(k["beta"]), b.norm,
             _hp(k["H"]), _hp(k["LRinv"]), likelihood.cR, _hp(k["m0"]), _hp(k["L0"]), _hp(k["y"]),
             _hp(k["u"]) if self.nu else None, self.device.index, 1 if keep_logw_trace else 0,
+            1 if os.environ.get("PGAS_NO_FAST_VARIANT", "0") == "1" else 0,
         )
         h = C.c_void_p()
         rc = self.lib.pgas_create(C.byref(d), C.byref(h))
@@ -425,7 +426,7 @@ class Engine:
         """dict(chunk, local_groups, JP, P) of the last sweep (pgas_get_launch_info)."""
         v = (C.c_int32 * 4)()
         self._chk(self.lib.pgas_get_launch_info(self._h, v), "pgas_get_launch_info")
-        return dict(chunk=int(v[0]), local_groups=bool(v[1]), JP=int(v[2]), P=int(v[3]))
+        return dict(chunk=int(v[0]), local_groups=int(v[1]) == 1, groups={0: "k_groups", 1: "local", 2: "tail"}[int(v[1])], JP=int(v[2]), P=int(v[3]))
 
     def shard_sweep(self, seed, ref, traj, propagate_chunk=0):
         self._ag_error = None

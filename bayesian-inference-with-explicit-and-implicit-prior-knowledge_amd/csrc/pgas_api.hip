@@ -22,6 +22,12 @@
 #ifndef PG_W28
 #define PG_W28 2
 #endif
+#ifndef PG_PPT27
+#define PG_PPT27 8   // particles per thread of that variant (two segments per workgroup: the whole grid is resident at once)
+#endif
+#ifndef PG_P27
+#define PG_P27 2   // particles per basis pass of the SingleMassOscillator-shaped FAST variant
+#endif
 #ifndef PG_P3
 #define PG_P3 1   // particles per basis pass of the 3-D variants: 1 keeps k_propagate at 164 VGPRs (3 waves/SIMD; 2 -> 209 VGPRs, 2 waves)
 #endif
@@ -87,17 +93,33 @@ typedef void (*basis_fn)(DevModel, const int32_t*, const double*, int64_t, int, 
 struct Variant {
     front_fn front;
     prop_fn prop;
+    prop_fn prop_one;   // instantiation for launches of exactly one time step (nullptr: use prop)
     aux_fn aux;
     int P, W;   // particles per basis pass, waves per SIMD the k_propagate instantiation is built for
+    int PPT;    // particles per thread of k_propagate: its grid is ceil(nseg / (PPT / 4))
 };
 
-template <int NX, int D, int JIN, int P, int W>
+template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT>
 Variant make_variant() {
-    return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W>, k_aux<NX, D, JIN, P>, P, W};
+    prop_fn one = nullptr;
+    if constexpr (J0T > 0) one = k_propagate<NX, D, JIN, P, W, J0T, PPT, true>;
+    return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W, J0T, PPT>, one, k_aux<NX, D, JIN, P>, P, W, PPT};
 }
 
 // (nx, D, padded innermost extent) -> kernel instantiation <NX, D, JIN, P particles per basis pass, W waves/SIMD>
-bool pick_variant(int nx, int D, int jin_needed, Variant* v, int* JP) {
+// `fast`: the model has the shape the FAST instantiations are compiled for (sel[d] == d, jstep == j0 in every dimension);
+// J0 = frequencies of the outermost dimension.  The reference's configurations: SingleMassOscillator 7 x 7, EMPS / Vehicle 9 x 9 x 9.
+bool pick_variant(int nx, int D, int jin_needed, bool fast, int J0, Variant* v, int* JP) {
+    if (fast && nx == 2 && D == 2 && jin_needed == 7 && J0 == 7) {
+        *JP = 7;
+        *v = make_variant<2, 2, 7, PG_P27, PG_W28, 7, PG_PPT27>();
+        return true;
+    }
+    if (fast && nx == 2 && D == 3 && jin_needed == 9 && J0 == 9) {
+        *JP = 9;
+        *v = make_variant<2, 3, 9, PG_P3, 2, 9>();
+        return true;
+    }
     if (D == 1) {
         *JP = 1;
         *v = nx == 1 ? make_variant<1, 1, 1, 4, 2>() : make_variant<2, 1, 1, 4, 2>();
@@ -170,6 +192,9 @@ struct pgas_ctx {
     int var_P = 0;              // particles per basis pass of the k_propagate variant
     unsigned launch_tag = 0;    // unique id per k_step launch (hand-off word tag)
     int force_slow = 0;         // 1: never let k_step scan the groups itself (test hook for the k_groups path taken when N > 2^20 per device)
+    int no_tail_groups = 0;     // PGAS_OPT_NO_TAIL_GROUPS: 1 = k_groups launches between the steps also on a single device (test / A-B knob)
+    int ev_stride = 8;          // PGAS_OPT_EVENT_STRIDE: k_propagate launches per event that gates the weight recursion
+    int local_groups = 0;       // PGAS_OPT_LOCAL_GROUPS: 1 = k_step<LOCAL> where it applies
     int overlap = 1;            // 1: run the weight recursion on an internal stream concurrently with k_propagate
     int prop_lds = 0;   // dynamic LDS reserved per k_propagate workgroup when overlapping: caps it at two workgroups per CU so
                                 // that two k_step workgroups always fit beside them
@@ -223,6 +248,8 @@ static int alloc_scanbufs(pgas_ctx* c, ScanBufs* sb) {
     HIPCHK(c, hipMalloc(&sb->tab_m, 2 * nsegp * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->grp_K, 2 * PG_MAX_GRP * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->grp_T, 2 * PG_MAX_GRP * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->grp_cnt, PG_MAX_GRP * sizeof(unsigned)));
+    HIPCHK(c, hipMemset(sb->grp_cnt, 0, PG_MAX_GRP * sizeof(unsigned)));
     HIPCHK(c, hipMalloc(&sb->hdr, sizeof(UpperHdr)));
     HIPCHK(c, hipMemset(sb->hdr, 0, sizeof(UpperHdr)));
     sb->segk = sb->segk_w;
@@ -234,7 +261,7 @@ static int alloc_scanbufs(pgas_ctx* c, ScanBufs* sb) {
 }
 static void free_scanbufs(ScanBufs* sb) {
     hipFree(sb->laux); hipFree(sb->c1); hipFree(sb->c2); hipFree(sb->segk_w); hipFree(sb->segs_w);  // segk/segs alias these or the gathered arrays
-    hipFree(sb->tab_e); hipFree(sb->tab_sc); hipFree(sb->tab_m); hipFree(sb->grp_K); hipFree(sb->grp_T); hipFree(sb->hdr);
+    hipFree(sb->tab_e); hipFree(sb->tab_sc); hipFree(sb->tab_m); hipFree(sb->grp_K); hipFree(sb->grp_T); hipFree(sb->grp_cnt); hipFree(sb->hdr);
     *sb = ScanBufs{};
 }
 
@@ -285,7 +312,9 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
     for (int j = 0; j < d->ny; ++j)
         for (int k = 0; k < d->nx; ++k) md.H[j * d->nx + k] = d->H[j * d->nx + k];
     for (int j = 0; j < d->ny * d->ny; ++j) md.LRinv[j] = d->LRinv[j];
-    if (!pick_variant(d->nx, d->D, md.J[d->D - 1], &c->var, &md.JP))
+    bool fast = !d->no_fast_variant;
+    for (int k = 0; k < d->D; ++k) fast = fast && md.sel[k] == k && md.jstep[k] == md.j0[k];
+    if (!pick_variant(d->nx, d->D, md.J[d->D - 1], fast, md.J[0], &c->var, &md.JP))
         FAIL(c, PGAS_E_ARG, "pgas_create: innermost basis dimension has %d frequencies (compiled up to 16)", md.J[d->D - 1]);
     c->var_P = c->var.P;
     c->back = d->nx == 1 ? k_back<1> : k_back<2>;
@@ -457,7 +486,13 @@ static int launch_count(pgas_ctx* c, const ScanBufs& sb, int parity, int what, d
     return PGAS_OK;
 }
 
-static bool sweep_is_local(const pgas_ctx* c) { return c->world == 1 && !c->sharded && c->md.nseg_g <= PG_LOCAL_NSEG && !c->force_slow; }
+// k_step<LOCAL> (every workgroup scans all groups itself, no k_groups launch between the steps) is an option, not the default:
+// measured at N = 2^20 the k_groups path is 9 % faster (81.4 against 90.2 ms per sweep; the redundant scans cost more vector
+// issue than the extra tiny launch costs latency).  PGAS_OPT_LOCAL_GROUPS selects it.
+static bool sweep_is_local(const pgas_ctx* c) { return c->local_groups && c->world == 1 && !c->sharded && c->md.nseg_g <= PG_LOCAL_NSEG && !c->force_slow; }
+
+// single device: the group scans ride in k_step's tail (no k_groups launch between the steps); sharded: they need the all-gather first
+static bool sweep_tail_groups(const pgas_ctx* c) { return !c->sharded && c->world == 1 && !c->no_tail_groups; }
 
 // launch t in [1, T] of the sweep: resamples step t-1 (t > 1), scans step t (t < T)
 static int launch_step(pgas_ctx* c, int t, uint64_t seed, bool local, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
@@ -482,8 +517,9 @@ static int launch_step(pgas_ctx* c, int t, uint64_t seed, bool local, hipStream_
     const ScanBufs& sp = c->sb[(t - 1) & 1];
     const ScanBufs& sn = c->sb[t & 1];
     const Peers pr = peers_for(c, (t - 1) & 1);
-    if (local) hipExtLaunchKernelGGL(k_step<true>, dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
-    else hipExtLaunchKernelGGL(k_step<false>, dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    if (local) hipExtLaunchKernelGGL((k_step<true, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    else if (sweep_tail_groups(c)) hipExtLaunchKernelGGL((k_step<false, true>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    else hipExtLaunchKernelGGL((k_step<false, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
     KCHK(c, "k_step");
     return PGAS_OK;
 }
@@ -541,8 +577,10 @@ static int ensure_traces(pgas_ctx* c) {
 
 // k_propagate for time steps [t0, t1), optionally carrying dispatch-attached events
 static int launch_propagate(pgas_ctx* c, uint64_t seed, int t0, int t1, const double* ref_dev, hipStream_t st, bool timed) {
-    const dim3 grid(c->md.nseg), blk(PG_BLK);
+    const int spw = c->var.PPT / PG_PPT;   // segments per k_propagate workgroup
+    const dim3 grid((c->md.nseg + spw - 1) / spw), blk(PG_BLK);
     const size_t lds = c->overlap ? c->prop_lds : 0;
+    const prop_fn prop = (t1 == t0 + 1 && c->var.prop_one) ? c->var.prop_one : c->var.prop;
     if (timed) {
         while ((int)c->evp.size() < c->evp_used + 2) {
             hipEvent_t e;
@@ -550,11 +588,11 @@ static int launch_propagate(pgas_ctx* c, uint64_t seed, int t0, int t1, const do
             c->evp.push_back(e);
         }
         // start/stop events bound to the dispatch itself: they carry the kernel's own begin/end timestamps
-        hipExtLaunchKernelGGL(c->var.prop, grid, blk, lds, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, c->md, c->tp, seed, t0, t1, c->x_trace,
+        hipExtLaunchKernelGGL(prop, grid, blk, lds, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, c->md, c->tp, seed, t0, t1, c->x_trace,
                               ref_dev, c->la_buf, c->h_buf, c->ln_buf);
         c->evp_used += 2;
     } else {
-        hipLaunchKernelGGL(c->var.prop, grid, blk, lds, st, c->md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
+        hipLaunchKernelGGL(prop, grid, blk, lds, st, c->md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
     }
     KCHK(c, "k_propagate");
     return PGAS_OK;
@@ -601,24 +639,31 @@ static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int 
         c->ev.resize(2 * (size_t)T);
         for (size_t i = old; i < c->ev.size(); ++i) HIPCHK(c, hipEventCreate(&c->ev[i]));
     }
-    // launches are issued chunk by chunk, pipeline A first, so both device queues stay fed
-    for (int ci = 0; ci < nchunk; ++ci) {
-        const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
-        int rc = launch_propagate(c, seed, t0, t1, ref_dev, st, c->profiling && (ci % c->prof_stride) == 0);
-        if (rc) return rc;
-        if (sB != st) {
-            HIPCHK(c, hipEventRecord(c->ev_chunk[ci], st));
-            HIPCHK(c, hipStreamWaitEvent(sB, c->ev_chunk[ci], 0));
+    // Launches are issued in groups of `ev_stride` chunks, pipeline A first, so both device queues stay fed.  One event per
+    // group (not per chunk) gates pipeline B: a marker packet between two consecutive k_propagate launches costs pipeline A a
+    // command-processor round trip per step, and B trails A by more than a group anyway.
+    const int stride = c->ev_stride > 0 ? c->ev_stride : 1;
+    for (int c0 = 0; c0 < nchunk; c0 += stride) {
+        const int c1 = c0 + stride < nchunk ? c0 + stride : nchunk;
+        for (int ci = c0; ci < c1; ++ci) {
+            const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
+            int rc = launch_propagate(c, seed, t0, t1, ref_dev, st, c->profiling && (ci % c->prof_stride) == 0);
+            if (rc) return rc;
         }
-        // launch t resamples step t-1 (t > 1) and scans step t (t < T); the last chunk also runs launch T
-        const int tend = ci == nchunk - 1 ? T + 1 : t1;
-        for (int t = t0; t < tend; ++t) {
+        if (sB != st) {
+            HIPCHK(c, hipEventRecord(c->ev_chunk[c0], st));
+            HIPCHK(c, hipStreamWaitEvent(sB, c->ev_chunk[c0], 0));
+        }
+        // launch t resamples step t-1 (t > 1) and scans step t (t < T); the last group also runs launch T
+        const int tbeg = 1 + c0 * chunk;
+        const int tend = c1 == nchunk ? T + 1 : 1 + c1 * chunk;
+        for (int t = tbeg; t < tend; ++t) {
             const bool timed = c->profiling && t < T && (t % c->prof_stride) == 0;
             hipEvent_t e0 = timed ? c->ev[c->ev_used] : (hipEvent_t) nullptr, e1 = timed ? c->ev[c->ev_used + 1] : (hipEvent_t) nullptr;
             if (timed) c->ev_used += 2;
-            rc = launch_step(c, t, seed, local, sB, e0, e1);
+            int rc = launch_step(c, t, seed, local, sB, e0, e1);
             if (rc) return rc;
-            if (!local && t < T) {
+            if (!local && t < T && !sweep_tail_groups(c)) {
                 if (c->sharded) {
                     rc = shard_all_gather(c, t & 1, sB);   // the one collective of the step, stream-ordered: no host round trip
                     if (rc) return rc;
@@ -751,6 +796,19 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         c->force_slow = value ? 1 : 0;
         return PGAS_OK;
     }
+    if (option == PGAS_OPT_NO_TAIL_GROUPS) {
+        c->no_tail_groups = value ? 1 : 0;
+        return PGAS_OK;
+    }
+    if (option == PGAS_OPT_EVENT_STRIDE) {
+        if (value < 1) FAIL(c, PGAS_E_ARG, "pgas_set_option: event stride must be >= 1");
+        c->ev_stride = (int)value;
+        return PGAS_OK;
+    }
+    if (option == PGAS_OPT_LOCAL_GROUPS) {
+        c->local_groups = value ? 1 : 0;
+        return PGAS_OK;
+    }
     if (option == PGAS_OPT_OVERLAP) {
         c->overlap = value ? 1 : 0;
         return PGAS_OK;
@@ -804,7 +862,7 @@ int pgas_get_launch_info(pgas_ctx* c, int32_t* info4) {
     if (!c) return PGAS_E_ARG;
     if (!info4) FAIL(c, PGAS_E_ARG, "pgas_get_launch_info: NULL argument");
     info4[0] = c->last_chunk;
-    info4[1] = sweep_is_local(c) ? 1 : 0;
+    info4[1] = sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0);
     info4[2] = c->md.JP;
     info4[3] = c->var_P;
     return PGAS_OK;

@@ -102,6 +102,7 @@ struct ScanBufs {      // per-step scan scratch (device)
     double* tab_m;     //              running maximum of the segment-end values inside the group
     double* grp_K;     // (2, PG_MAX_GRP) group references KG
     double* grp_T;     // (2, PG_MAX_GRP) group totals TG
+    unsigned* grp_cnt; // (PG_MAX_GRP) arrival counters of k_step's in-launch group scans (zero between uses)
     UpperHdr* hdr;
 };
 
@@ -191,6 +192,27 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return __builtin_amdgcn_readlane(v, 63);
 }
 
+// FAST instantiations (template parameter J0T > 0 of eval_mean / k_propagate): the model's shape is known at compile time --
+// basis input d is component d of concat(state, input) (sel[d] == d), every dimension's frequencies are j0, 2 j0, 3 j0, ...
+// (jstep == j0: one sincospi per dimension, Chebyshev recurrence starting from 0), the outermost dimension has exactly J0T
+// frequencies.  Same arithmetic, fewer branches, moves and scalar registers.  Every configuration of the reference has this shape.
+template <int NX, int DSEL>
+__device__ __forceinline__ double pick_input_fixed(const double (&x)[NX], const double* __restrict__ ut) {
+    if constexpr (DSEL < NX) return x[DSEL];
+    else return ut[DSEL - NX];
+}
+
+template <int NX>
+__device__ __forceinline__ double pick_input(const DevModel& md, int d, const double (&x)[NX], const double* __restrict__ ut);
+// r_d = v[sel[d]] alpha_d + beta_d, the argument of dimension d's sines in units of pi
+template <int NX, int DSEL, bool FAST>
+__device__ __forceinline__ double basis_arg(const DevModel& md, const double (&x)[NX], const double* __restrict__ ut) {
+    double v;
+    if constexpr (FAST) v = pick_input_fixed<NX, DSEL>(x, ut);
+    else v = pick_input<NX>(md, DSEL, x, ut);
+    return PGAS_FMA(v, md.alpha[DSEL], md.beta[DSEL]);
+}
+
 template <int NX>
 __device__ __forceinline__ double pick_input(const DevModel& md, int d, const double (&x)[NX], const double* __restrict__ ut) {
     const int s = md.sel[d];
@@ -234,7 +256,7 @@ struct DimStart {
 };
 
 // start / step sines of dimension d for P particles at once (batch form keeps polynomial coefficients in registers)
-template <int P>
+template <int P, bool FAST = false>
 __device__ __forceinline__ void dim_start_n(const DevModel& md, int d, const double (&r)[P], DimStart (&ds)[P]) {
     double a[P], sv[P], cv[P];
 #pragma unroll
@@ -247,7 +269,7 @@ __device__ __forceinline__ void dim_start_n(const DevModel& md, int d, const dou
         ds[p].sd = sv[p];
         ds[p].cd = cv[p];
     }
-    if (md.jstep[d] != md.j0[d]) {  // uniform
+    if (!FAST && md.jstep[d] != md.j0[d]) {  // uniform
 #pragma unroll
         for (int p = 0; p < P; ++p) a[p] = (double)md.jstep[d] * r[p];
         pgas_sincospi_n(a, sv, cv, P);
@@ -268,10 +290,11 @@ __device__ __forceinline__ void rotate(double& sc, double& cc, double sd, double
 struct Cheb {
     double cur, prev, tw;
 };
+template <bool FAST = false>
 __device__ __forceinline__ Cheb cheb_init(const DevModel& md, int d, const DimStart& ds) {
     Cheb c;
     c.cur = ds.s0;
-    c.prev = (md.jstep[d] == md.j0[d]) ? 0.0 : PGAS_FMA(ds.s0, ds.cd, -(ds.c0 * ds.sd));
+    c.prev = (FAST || md.jstep[d] == md.j0[d]) ? 0.0 : PGAS_FMA(ds.s0, ds.cd, -(ds.c0 * ds.sd));
     c.tw = ds.cd + ds.cd;
     return c;
 }
@@ -287,9 +310,10 @@ __device__ __forceinline__ void cheb_next(Cheb& c) {
 // dense frequency grid; the coefficients are wave-uniform (scalar loads), the outer dimensions'
 // sines come from a recurrence, only the innermost dimension's table lives in registers.
 // ------------------------------------------------------------------------------------------
-template <int NX, int D, int JIN, int P>
+template <int NX, int D, int JIN, int P, int J0T = 0>
 __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __restrict__ G, const double* __restrict__ ut,
                                           const double (&x)[P][NX], double (&aux)[P][NX]) {
+    constexpr bool FAST = J0T > 0;
 #pragma unroll
     for (int p = 0; p < P; ++p)
 #pragma unroll
@@ -298,9 +322,9 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
         double r[P];
         DimStart ds[P];
 #pragma unroll
-        for (int p = 0; p < P; ++p) r[p] = PGAS_FMA(pick_input<NX>(md, 0, x[p], ut), md.alpha[0], md.beta[0]);
-        dim_start_n<P>(md, 0, r, ds);
-        const int J0 = md.J[0];
+        for (int p = 0; p < P; ++p) r[p] = basis_arg<NX, 0, FAST>(md, x[p], ut);
+        dim_start_n<P, FAST>(md, 0, r, ds);
+        const int J0 = FAST ? J0T : md.J[0];
         for (int a = 0; a < J0; ++a) {
             double g[NX];
 #pragma unroll
@@ -322,25 +346,25 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
             DimStart din[P], dout[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                rin[p] = PGAS_FMA(pick_input<NX>(md, DI, x[p], ut), md.alpha[DI], md.beta[DI]);
-                rout[p] = PGAS_FMA(pick_input<NX>(md, 0, x[p], ut), md.alpha[0], md.beta[0]);
+                rin[p] = basis_arg<NX, DI, FAST>(md, x[p], ut);
+                rout[p] = basis_arg<NX, 0, FAST>(md, x[p], ut);
             }
-            dim_start_n<P>(md, DI, rin, din);
-            dim_start_n<P>(md, 0, rout, dout);
+            dim_start_n<P, FAST>(md, DI, rin, din);
+            dim_start_n<P, FAST>(md, 0, rout, dout);
 #pragma unroll
             for (int p = 0; p < P; ++p) {
-                Cheb ci = cheb_init(md, DI, din[p]);
+                Cheb ci = cheb_init<FAST>(md, DI, din[p]);
 #pragma unroll
                 for (int q = 0; q < JIN; ++q) {
                     tab[p][q] = ci.cur;
                     cheb_next(ci);
                 }
-                c0[p] = cheb_init(md, 0, dout[p]);
+                c0[p] = cheb_init<FAST>(md, 0, dout[p]);
             }
         }
-        const int J0 = md.J[0];
+        const int J0 = FAST ? J0T : md.J[0];
         if constexpr (D == 2) {
-            for (int a = 0; a < J0; ++a) {
+            auto body = [&](int a) {
                 double in[P][NX];
 #pragma unroll
                 for (int p = 0; p < P; ++p)
@@ -362,6 +386,47 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
                     for (int k = 0; k < NX; ++k) aux[p][k] = PGAS_FMA(c0[p].cur, in[p][k], aux[p][k]);
                     cheb_next(c0[p]);
                 }
+            };
+            if constexpr (FAST) {
+                // Kept rolled (unrolled, the compiler hoists all J0T x JIN x NX coefficient loads to the top and spills ~290 SGPRs)
+                // and software-pipelined by hand: the scalar loads of row a + 1 are issued before the FMAs of row a, so their
+                // latency hides under 38 vector instructions instead of stalling every iteration.
+                double g[JIN * NX];
+#pragma unroll
+                for (int i = 0; i < JIN * NX; ++i) g[i] = G[i];
+#ifdef PG_X_SHORTLOOP
+                constexpr int J0X = 1;
+#else
+                constexpr int J0X = J0T;
+#endif
+#pragma unroll 1
+                for (int a = 0; a < J0X; ++a) {
+                    const double* __restrict__ Gn = G + (size_t)(a + 1 < J0T ? a + 1 : a) * JIN * NX;
+                    double gn[JIN * NX];
+#pragma unroll
+                    for (int i = 0; i < JIN * NX; ++i) gn[i] = Gn[i];
+                    double in[P][NX];
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) in[p][k] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < JIN; ++q)
+#pragma unroll
+                        for (int k = 0; k < NX; ++k)
+#pragma unroll
+                            for (int p = 0; p < P; ++p) in[p][k] = PGAS_FMA(g[q * NX + k], tab[p][q], in[p][k]);
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) aux[p][k] = PGAS_FMA(c0[p].cur, in[p][k], aux[p][k]);
+                        cheb_next(c0[p]);
+                    }
+#pragma unroll
+                    for (int i = 0; i < JIN * NX; ++i) g[i] = gn[i];
+                }
+            } else {
+                for (int a = 0; a < J0; ++a) body(a);
             }
         } else {
             Cheb c1s[P];
@@ -369,10 +434,10 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
                 double r1[P];
                 DimStart d1[P];
 #pragma unroll
-                for (int p = 0; p < P; ++p) r1[p] = PGAS_FMA(pick_input<NX>(md, 1, x[p], ut), md.alpha[1], md.beta[1]);
-                dim_start_n<P>(md, 1, r1, d1);
+                for (int p = 0; p < P; ++p) r1[p] = basis_arg<NX, 1, FAST>(md, x[p], ut);
+                dim_start_n<P, FAST>(md, 1, r1, d1);
 #pragma unroll
-                for (int p = 0; p < P; ++p) c1s[p] = cheb_init(md, 1, d1[p]);
+                for (int p = 0; p < P; ++p) c1s[p] = cheb_init<FAST>(md, 1, d1[p]);
             }
             const int J1 = md.J[1];
             for (int a = 0; a < J0; ++a) {
@@ -526,7 +591,9 @@ struct ScanSmem {
     uint64_t wtot[2][PG_BLK / 64];
 };
 
-template <int NW, bool STORE_B = true>  // NW: weight vectors scanned together (1 or 2); STORE_B = false: the second one only leaves its
+// HANDOFF: the segment partials are stored write-through (agent-scope 8-byte stores) because another workgroup of the SAME launch
+// reads them (the last arriver of the group, k_step); a plain store otherwise (the next launch reads them).
+template <int NW, bool STORE_B = true, bool HANDOFF = false>  // NW: weight vectors scanned together (1 or 2); STORE_B = false: the second one only leaves its
                                          // segment partial (max, total) -- its per-particle cumsum is recomputed where it is needed
 __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW][PG_PPT], int seg, int nsegp,
                                              uint64_t* __restrict__ cA, uint64_t* __restrict__ cB, double* __restrict__ segm,
@@ -597,8 +664,13 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
             dst[1] = make_ulonglong2(base + loc[w][2], base + loc[w][3]);
         }
         if (tid == 0) {
-            segm[(size_t)w * nsegp + seg] = mx[w];
-            segs[(size_t)w * nsegp + seg] = tot;
+            if constexpr (HANDOFF) {
+                __hip_atomic_store(&segm[(size_t)w * nsegp + seg], mx[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&segs[(size_t)w * nsegp + seg], tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                segm[(size_t)w * nsegp + seg] = mx[w];
+                segs[(size_t)w * nsegp + seg] = tot;
+            }
         }
     }
 }
@@ -610,7 +682,7 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
 // resampled ancestors (quirk Q1), which is what lets the sweep run this part for all time steps
 // without any synchronisation (k_propagate).
 // ------------------------------------------------------------------------------------------
-template <int NX, int D, int JIN, int P>
+template <int NX, int D, int JIN, int P, int J0T = 0>
 __device__ __forceinline__ void propagate_particles(const DevModel& md, const TransParams& tp, int t, uint64_t seed,
                                                     const double* __restrict__ ref_t, int seg, const double (&xprev)[PG_PPT][NX],
                                                     double (&xnew)[PG_PPT][NX], double (&la)[PG_PPT], double (&h)[PG_PPT],
@@ -628,7 +700,7 @@ __device__ __forceinline__ void propagate_particles(const DevModel& md, const Tr
         for (int p = 0; p < P; ++p)
 #pragma unroll
             for (int k = 0; k < NX; ++k) xin[p][k] = xprev[r0 + p][k];
-        eval_mean<NX, D, JIN, P>(md, tp.G, ut, xin, ax);
+        eval_mean<NX, D, JIN, P, J0T>(md, tp.G, ut, xin, ax);
 #pragma unroll
         for (int p = 0; p < P; ++p)
 #pragma unroll
@@ -756,28 +828,169 @@ __global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, TransParams tp, i
 // k_resample   one launch per time step: systematic-resampling search of step t-1 (needs k_upper(t-1)),
 //              logw_{t-1} = ln_{t-1} - la_{t-1}[a], then both softmax scans of step t.
 // ------------------------------------------------------------------------------------------
-template <int NX, int D, int JIN, int P, int W>
+// One group of P particles of this thread through one time step, start to finish (basis, transition mean, noise, the three
+// log-densities, new state): the FAST k_propagate walks its PG_PPT particles group by group so that only one group's
+// intermediates are live at a time (the all-at-once form needs ~165 VGPRs, this one fits four waves per SIMD).
+template <int NX, int D, int JIN, int P, int J0T>
+__device__ __forceinline__ void propagate_group(const DevModel& md, const TransParams& tp, int t, uint64_t seed, const double (&rf)[NX],
+                                                const double* __restrict__ yt, const double* __restrict__ ut, int seg, int r0,
+                                                const double (&xin)[P][NX], double (&xn)[P][NX], double (&la)[P], double (&h)[P], double (&ln)[P]) {
+    const int tid = threadIdx.x;
+    double aux[P][NX];
+    eval_mean<NX, D, JIN, P, J0T>(md, tp.G, ut, xin, aux);
+    double z0[P], z1[P];
+    {
+        pgas_u32x4 w[P];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            const int64_t pi = (int64_t)seg * PGAS_SEG + (r0 + p) * PG_BLK + tid;
+#ifdef PG_X_NOPHILOX
+            w[p].v[0] = (uint32_t)pi * 2654435761u; w[p].v[1] = (uint32_t)t + 12345u; w[p].v[2] = (uint32_t)pi ^ 0x9e3779b9u; w[p].v[3] = (uint32_t)seed;
+#else
+            w[p] = pgas_rng_block(seed, PGAS_STREAM_PROP, 0u, (uint32_t)t, (uint64_t)(md.p0 + pi));
+#endif
+        }
+#ifdef PG_X_NOBM
+#pragma unroll
+        for (int p = 0; p < P; ++p) { z0[p] = (double)w[p].v[0] * 0x1p-32; z1[p] = (double)w[p].v[2] * 0x1p-32; }
+#else
+        pgas_normal_pair_n(w, z0, z1, P);
+#endif
+    }
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        const int64_t pi = (int64_t)seg * PGAS_SEG + (r0 + p) * PG_BLK + tid;
+        la[p] = loglik<NX>(md, yt, aux[p]);
+        double quad = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            double w = 0.0;
+#pragma unroll
+            for (int l = 0; l <= k; ++l) w = PGAS_FMA(tp.LSinv[k * NX + l], rf[l] - aux[p][l], w);
+            quad = PGAS_FMA(w, w, quad);
+        }
+        h[p] = PGAS_FMA(-0.5, quad, tp.cS);
+        const double z[2] = {z0[p], z1[p]};
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            double v = aux[p][k];
+#pragma unroll
+            for (int l = 0; l <= k; ++l) v = PGAS_FMA(tp.LS[k * NX + l], z[l], v);
+            xn[p][k] = (md.p0 + pi == md.Ng - 1) ? rf[k] : v;
+        }
+        ln[p] = loglik<NX>(md, yt, xn[p]);
+    }
+}
+
+// PPT = particles per thread.  The generic instantiations take PG_PPT = 4 (one segment per workgroup, grid = nseg).  The FAST ones
+// take 8 (two segments per workgroup, grid = ceil(nseg / 2)): at ~156 VGPRs three waves fit a SIMD, so 1024 four-wave workgroups
+// need 1.33 rounds and the last third of the grid runs alone, one wave per SIMD, exposing every dependent-issue latency --
+// the kernel took 25.6 us for 16 us of vector issue.  512 workgroups of twice the work are resident all at once.
+// ONE = the launch covers exactly one time step (t1 == t0 + 1; what the sweep uses for the cheap bases): a group's state is then
+// loaded right before its pass instead of being held for the whole launch (8 particles x 2 doubles = 32 VGPRs less).
+template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT, bool ONE = false>
 __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParams tp, uint64_t seed, int t0, int t1,
                                                           double* __restrict__ x_trace, const double* __restrict__ ref,
                                                           double* __restrict__ la_buf, double* __restrict__ h_buf,
                                                           double* __restrict__ ln_buf) {
-    const int seg = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const size_t row = (size_t)md.N * NX, np = (size_t)md.nseg * PGAS_SEG;
-    double xv[PG_PPT][NX];
-    load_particles<NX>(md, x_trace + (size_t)(t0 - 1) * row, seg, xv);
-    for (int t = t0; t < t1; ++t) {
-        double xn[PG_PPT][NX], la[PG_PPT], h[PG_PPT], aux[PG_PPT][NX];
-        propagate_particles<NX, D, JIN, P>(md, tp, t, seed, ref + (size_t)t * NX, seg, xv, xn, la, h, aux);
-        store_particles<NX>(md, x_trace + (size_t)t * row, seg, xn);
-        const double* __restrict__ yt = md.y + (size_t)t * md.ny;
+    if constexpr (J0T > 0) {
+        static_assert(PPT % PG_PPT == 0 && PPT % P == 0, "whole segments per workgroup, whole groups per thread");
+        const int seg0 = blockIdx.x * (PPT / PG_PPT);
+        // particle r of this thread: segment seg0 + r / 4, row (r % 4) * 256 + tid inside it (the layout every other kernel uses)
+        auto particle = [&](int r) { return (size_t)(seg0 + r / PG_PPT) * PGAS_SEG + (size_t)(r % PG_PPT) * PG_BLK + tid; };
+        auto load_state = [&](int r, double (&xr)[NX]) {
+            size_t pi = particle(r);
+            if (pi >= (size_t)md.N) pi = md.N - 1;
+            if constexpr (NX == 2) {
+                const double2 v = reinterpret_cast<const double2*>(x_trace + (size_t)(t0 - 1) * row)[pi];
+                xr[0] = v.x;
+                xr[1] = v.y;
+            } else {
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
-            const size_t pi = (size_t)seg * PGAS_SEG + r * PG_BLK + tid;  // buffers are padded to nseg*SEG
-            la_buf[(size_t)t * np + pi] = la[r];
-            h_buf[(size_t)t * np + pi] = h[r];
-            ln_buf[(size_t)t * np + pi] = loglik<NX>(md, yt, xn[r]);
+                for (int k = 0; k < NX; ++k) xr[k] = x_trace[(size_t)(t0 - 1) * row + pi * NX + k];
+            }
+        };
+        double xv[ONE ? 1 : PPT][NX];
+        if constexpr (!ONE) {
 #pragma unroll
-            for (int k = 0; k < NX; ++k) xv[r][k] = xn[r][k];
+            for (int r = 0; r < PPT; ++r) load_state(r, xv[r]);
+        }
+        for (int t = t0; t < (ONE ? t0 + 1 : t1); ++t) {
+            const double* __restrict__ yt = md.y + (size_t)t * md.ny;
+            const double* __restrict__ ut = md.u + (size_t)t * md.nu;
+            double rf[NX];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) rf[k] = ref[(size_t)t * NX + k];
+            double* __restrict__ xt = x_trace + (size_t)t * row;
+            // ONE: kept rolled -- four unrolled copies of the pass are 35 KB of code, and k_step's 60 KB run beside it on an
+            // instruction cache of 64 KB per CU pair
+            constexpr int kUnroll = ONE ? 1 : PPT / P;
+            double xnext[P][NX];   // ONE: state of the NEXT group, loaded while this one computes (its HBM latency would otherwise
+                                    // be exposed once per group: nothing else in this kernel waits on memory)
+            if constexpr (ONE) {
+#pragma unroll
+                for (int p = 0; p < P; ++p) load_state(p, xnext[p]);
+            }
+#pragma unroll kUnroll
+            for (int r0 = 0; r0 < PPT; r0 += P) {
+                if (seg0 + r0 / PG_PPT >= md.nseg) break;   // uniform: odd segment count, second half of the last workgroup
+                double xin[P][NX], xn[P][NX], la[P], h[P], ln[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) xin[p][k] = ONE ? xnext[p][k] : xv[ONE ? 0 : r0 + p][k];
+                }
+                if constexpr (ONE) {
+                    const int rn = r0 + P < PPT ? r0 + P : r0;   // the last group re-reads its own rows (harmless, keeps the loop uniform)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) load_state(rn + p, xnext[p]);
+                }
+                propagate_group<NX, D, JIN, P, J0T>(md, tp, t, seed, rf, yt, ut, seg0 + r0 / PG_PPT, r0 % PG_PPT, xin, xn, la, h, ln);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const size_t pi = particle(r0 + p);   // la / h / ln are padded to nseg*SEG
+                    if (pi < (size_t)md.N) {
+                        if constexpr (NX == 2) {
+                            reinterpret_cast<double2*>(xt)[pi] = make_double2(xn[p][0], xn[p][1]);
+                        } else {
+#pragma unroll
+                            for (int k = 0; k < NX; ++k) xt[pi * NX + k] = xn[p][k];
+                        }
+                    }
+#ifdef PG_X_NOSTORE   // timing experiment only: keep the values live, skip the hand-off stores
+                    asm volatile("" ::"v"(la[p]), "v"(h[p]), "v"(ln[p]));
+#else
+                    la_buf[(size_t)t * np + pi] = la[p];
+                    h_buf[(size_t)t * np + pi] = h[p];
+                    ln_buf[(size_t)t * np + pi] = ln[p];
+#endif
+                    if constexpr (!ONE) {
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) xv[r0 + p][k] = xn[p][k];
+                    }
+                }
+            }
+        }
+    } else {
+        const int seg = blockIdx.x;
+        double xv[PG_PPT][NX];
+        load_particles<NX>(md, x_trace + (size_t)(t0 - 1) * row, seg, xv);
+        for (int t = t0; t < t1; ++t) {
+            const double* __restrict__ yt = md.y + (size_t)t * md.ny;
+            double xn[PG_PPT][NX], la[PG_PPT], h[PG_PPT], aux[PG_PPT][NX];
+            propagate_particles<NX, D, JIN, P, J0T>(md, tp, t, seed, ref + (size_t)t * NX, seg, xv, xn, la, h, aux);
+            store_particles<NX>(md, x_trace + (size_t)t * row, seg, xn);
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) {
+                const size_t pi = (size_t)seg * PGAS_SEG + r * PG_BLK + tid;  // buffers are padded to nseg*SEG
+                la_buf[(size_t)t * np + pi] = la[r];
+                h_buf[(size_t)t * np + pi] = h[r];
+                ln_buf[(size_t)t * np + pi] = loglik<NX>(md, yt, xn[r]);
+#pragma unroll
+                for (int k = 0; k < NX; ++k) xv[r][k] = xn[r][k];
+            }
         }
     }
 }

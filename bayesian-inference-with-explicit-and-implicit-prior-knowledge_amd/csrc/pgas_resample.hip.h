@@ -98,19 +98,21 @@ __device__ __forceinline__ double num_of(uint64_t c, const SegParams& p) {
 // ------------------------------------------------------------------------------------------
 // k_groups
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_groups(int nseg, int ncdf, ScanBufs sb) {
+// group scan of (cdf, g) by the calling wave: per-segment records and the group record
+__device__ __forceinline__ void group_records_wave(const ScanBufs& sb, int nseg, int cdf, int g, bool coherent) {
     const int lane = threadIdx.x & 63;
-    const int n1 = (nseg + PG_GRP - 1) / PG_GRP;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= n1 * ncdf) return;
-    const int cdf = w / n1, g = w % n1;
     const int b = g * PG_GRP + lane;
     double kk = -__builtin_inf();
     uint64_t ss = 0;
     if (b < nseg) {
         const size_t at = partial_at(sb, cdf, b);
-        kk = sb.segk[at];
-        ss = sb.segs[at];
+        if (coherent) {   // written by other workgroups of this launch: agent-scope loads behind the caller's acquire
+            kk = __hip_atomic_load(&sb.segk[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ss = __hip_atomic_load(&sb.segs[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            kk = sb.segk[at];
+            ss = sb.segs[at];
+        }
     }
     double e, sc, m, Kg;
     group_scan_wave(kk, ss, e, sc, m, Kg);
@@ -126,6 +128,13 @@ __global__ __launch_bounds__(256) void k_groups(int nseg, int ncdf, ScanBufs sb)
         sb.grp_K[cdf * PG_MAX_GRP + g] = Kg;
         sb.grp_T[cdf * PG_MAX_GRP + g] = Tg;
     }
+}
+
+__global__ __launch_bounds__(256) void k_groups(int nseg, int ncdf, ScanBufs sb) {
+    const int n1 = (nseg + PG_GRP - 1) / PG_GRP;
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= n1 * ncdf) return;
+    group_records_wave(sb, nseg, w / n1, w % n1, false);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -747,11 +756,17 @@ __device__ PG_COLD_ATTR int cdf_count_wg_cold(WinSmemT<LOCAL>& sm, const ScanBuf
     return cdf_count_wg<LOCAL>(sm, sb, pr, 1, nseg, N, U, nullptr, nullptr, &in);
 }
 
-template <bool LOCAL>
+// TAIL (single device, not LOCAL): the group scans of step t run inside this launch -- the workgroup that completes a group of
+// 64 segments (arrival counter) scans it -- instead of a k_groups launch between two k_step launches.  Hand-off per
+// cdna_hip_programming.md Guideline 16 (write-through payload, drained, then the counter; the last arriver acquires).
+template <bool LOCAL, bool TAIL = false>
 __global__ __launch_bounds__(PG_BLK, 5) void k_step(DevModel md, StepArgs ar, ScanBufs sb_prev, ScanBufs sb_next, Peers pr) {
     __shared__ WinSmemT<LOCAL> sm;
     const int tid = threadIdx.x;
     const int N = md.N;
+#ifdef PG_STEP_PRIO
+    __builtin_amdgcn_s_setprio(PG_STEP_PRIO);   // the weight recursion is the latency chain of the sweep: let its few vector instructions go first
+#endif
     if (blockIdx.x == 0) {  // ---- ancestor workgroup
         if (!(ar.mode & PG_RS_SEARCH)) return;
         const int r = cdf_count_wg<LOCAL>(sm, sb_prev, pr, 1, md.nseg_g, md.Ng, ar.u2_prev, nullptr, nullptr, &ar.anc_in);
@@ -835,7 +850,26 @@ __global__ __launch_bounds__(PG_BLK, 5) void k_step(DevModel md, StepArgs ar, Sc
             lw[1][r] = valid_p ? l1 + ar.h_t[pi] : -__builtin_inf();
         }
         PG_STAMP(6);
-        segment_scan<2, false>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segk_w, sb_next.segs_w);
+        segment_scan<2, false, TAIL>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segk_w, sb_next.segs_w);
+        if constexpr (TAIL) {
+            if (tid < 64) {   // wave 0: lane 0 stored the partials above
+                const int g = seg / PG_GRP;
+                const int nb = md.nseg - g * PG_GRP < PG_GRP ? md.nseg - g * PG_GRP : PG_GRP;
+                unsigned arrived = 0;
+                if (tid == 0) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the write-through stores have left before the counter moves
+                    arrived = __hip_atomic_fetch_add(&sb_next.grp_cnt[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                arrived = __builtin_amdgcn_readfirstlane(arrived);
+                if (arrived == (unsigned)(nb - 1)) {   // this workgroup completed group g: scan it for both CDFs
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    group_records_wave(sb_next, md.nseg, 0, g, true);
+                    group_records_wave(sb_next, md.nseg, 1, g, true);
+                    if (tid == 0) __hip_atomic_store(&sb_next.grp_cnt[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the launch after next
+                }
+            }
+        }
     }
     PG_STAMP(7);
 }

@@ -218,7 +218,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=20, help="steps of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--chunk", type=int, default=-1, help="time steps per k_propagate launch (engine default if < 0)")
-    ap.add_argument("--force-groups", action="store_true", help="run k_groups between the steps even where k_step could scan the groups itself")
+    ap.add_argument("--no-tail-groups", action="store_true", help="k_groups as its own launch between the steps instead of in k_step's tail")
+    ap.add_argument("--local-groups", action="store_true", help="k_step<LOCAL>: every workgroup scans all groups itself instead of a k_groups launch between the steps")
+    ap.add_argument("--event-stride", type=int, default=-1, help="k_propagate launches per gating event (engine default if < 0)")
     ap.add_argument("--no-overlap", action="store_true", help="run the weight recursion on the caller's stream (no concurrency)")
     ap.add_argument("--prop-lds", type=int, default=-1, help="LDS bytes reserved per k_propagate workgroup while overlapping (engine default if < 0)")
     ap.add_argument("--workload", choices=["smo", "vehicle", "emps", "smo-alg1"], default="smo",
@@ -293,8 +295,12 @@ def main():
         eng = pg.cSMC.engine
     if args.chunk >= 0:
         eng.set_option(1, args.chunk)      # PGAS_OPT_PROPAGATE_CHUNK
-    if args.force_groups:
-        eng.set_option(2, 1)               # PGAS_OPT_FORCE_SLOW_RESAMPLE
+    if args.local_groups:
+        eng.set_option(7, 1)               # PGAS_OPT_LOCAL_GROUPS
+    if args.no_tail_groups:
+        eng.set_option(9, 1)               # PGAS_OPT_NO_TAIL_GROUPS
+    if args.event_stride > 0:
+        eng.set_option(8, args.event_stride)   # PGAS_OPT_EVENT_STRIDE
     if args.no_overlap:
         eng.set_option(3, 0)               # PGAS_OPT_OVERLAP
     if args.prop_lds >= 0:
@@ -368,7 +374,7 @@ def main():
             p_us = 1e3 * prop_ms / max(prop_n, 1)
             p_steps = max(info["chunk"], 1)
             p_us_step = p_us / p_steps
-            kname_step = "k_step<LOCAL>" if info["local_groups"] else "k_step + k_groups"
+            kname_step = {"local": "k_step<LOCAL>", "tail": "k_step<TAIL>", "k_groups": "k_step (+ k_groups launch)"}[info["groups"]]
             nxv, Dv = pb.nx, len(pb.basis_fcn.sel)
             kname_prop = f"k_propagate<{nxv},{Dv},{info['JP']},{info['P']}>"
             per_launch = ALG_BYTES_PER_PARTICLE_STEP * N

@@ -70,6 +70,7 @@ typedef struct pgas_model_desc {
     const double* u;      /* host (T,nu)    inputs; may be NULL when nu == 0 */
     int32_t device;       /* HIP device ordinal */
     int32_t keep_logw_trace; /* 1: keep the (T,N) log-weight trace like src/PGAS.py:163 (costs 8 B/particle-step) */
+    int32_t no_fast_variant; /* test knob: 1 = never use the k_propagate instantiations specialised for the reference's model shapes */
 } pgas_model_desc;
 
 /* Replaces condSequentialMonteCarlo.__init__ (src/PGAS.py:24-43) / PGAS.__init__ (:237-260):
@@ -127,21 +128,25 @@ int pgas_last_final_index(pgas_ctx* ctx, int64_t* idx, void* stream);
 int pgas_set_profiling(pgas_ctx* ctx, int32_t on);
 int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample_ms, int64_t* propagate_launches,
                      double* propagate_ms, void* stream);
-/* What the last sweep launched: info4 = {time steps per k_propagate launch, 1 if k_step scanned the groups itself (0: k_groups
- * ran between the steps), padded innermost basis extent JP, particles per basis pass P} -- bench.py labels its kernels from this. */
+/* What the last sweep launched: info4 = {time steps per k_propagate launch, group-scan placement (0: k_groups launches between the
+ * steps, 1: k_step<LOCAL> scans all groups in every workgroup, 2: in k_step's tail by the workgroup that completes a group),
+ * padded innermost basis extent JP, particles per basis pass P} -- bench.py labels its kernels from this. */
 int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 
 /* Tuning / test knobs.  PGAS_OPT_PROPAGATE_CHUNK: time steps per k_propagate launch (0 = the whole sweep in one launch). */
 #define PGAS_OPT_PROPAGATE_CHUNK 1
 #define PGAS_OPT_PROPAGATE_LDS 4 /* bytes of LDS reserved per k_propagate workgroup while overlapping (occupancy cap) */
 #define PGAS_OPT_OVERLAP 3 /* 1 (default): weight recursion on an internal stream, concurrent with k_propagate */
-#define PGAS_OPT_FORCE_SLOW_RESAMPLE 2 /* 1: always run k_groups between the steps (the path taken when N > 2^20 per device or sharded) */
+#define PGAS_OPT_FORCE_SLOW_RESAMPLE 2 /* 1: never take k_step<LOCAL> (overrides PGAS_OPT_LOCAL_GROUPS; kept for the tests) */
 /* 1: CORRECTED mode, not the reference's behaviour.  src/PGAS.py:131-133 propagates every particle from its own previous
  * state (`state`, not `state[a_indices]`) although the ancestors are recorded and used for the weights and the
  * back-trace.  With this option pgas_step / pgas_sweep draw x_t[i] ~ N(A phi(x_{t-1}[a_i]), S) as a particle filter should
  * (and as src/Algorithm1.py:286-292 does).  Same random numbers, same weight formula; the step becomes a serial chain of
  * three launches.  Default 0 = reproduce the reference. */
 #define PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE 5
+#define PGAS_OPT_LOCAL_GROUPS 7 /* 1: on a single device with <= 1024 segments every k_step workgroup scans all groups itself (k_step<LOCAL>, no k_groups launch between the steps); default 0, the k_groups path is faster */
+#define PGAS_OPT_NO_TAIL_GROUPS 9 /* 1: run k_groups as its own launch between the steps also on a single device (default 0: the group scans ride in k_step's tail) */
+#define PGAS_OPT_EVENT_STRIDE 8 /* k_propagate launches per event that gates the weight recursion's stream (default 8) */
 #define PGAS_OPT_MNIW_VALU 6 /* 1: pgas_m_mniw_solve factorises column by column on the VALU instead of in MFMA-blocked panels (test knob) */
 int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
 

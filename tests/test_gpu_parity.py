@@ -79,8 +79,9 @@ def test_basis_init_step_bit_exact(name, N):
 
 @pytest.mark.parametrize("name,N,opts", [
     ("smo", 200, {}), ("smo", 4096, {}), ("smo", 5000, {}), ("toy", 1500, {}), ("emps", 2048, {}), ("veh", 2048, {}), ("veh27", 3000, {}), ("smo", 1 << 17, {}),
-    ("smo", 5000, {2: 1}),            # PGAS_OPT_FORCE_SLOW_RESAMPLE: the k_resample + k_upper pair used when N > 2^20 per device
-    ("smo", 70000, {2: 1, 1: 7}),     # ... with k_propagate launched in chunks of 7 time steps
+    ("smo", 5000, {7: 1}),            # PGAS_OPT_LOCAL_GROUPS: k_step<LOCAL>, every workgroup scans all groups itself
+    ("smo", 70000, {7: 1, 1: 7}),     # ... with k_propagate launched in chunks of 7 time steps
+    ("smo", 1 << 17, {7: 1}),         # ... two groups
     ("toy", 1500, {1: 1}),            # PGAS_OPT_PROPAGATE_CHUNK = 1: one k_propagate launch per step
 ])
 def test_sweep_bit_exact(name, N, opts):
@@ -102,6 +103,24 @@ def test_sweep_bit_exact(name, N, opts):
         assert np.array_equal(Xn[t, b], trajo[t].reshape(-1))
         if t:
             b = An[t - 1, b]
+
+
+@pytest.mark.parametrize("name,N", [("smo", 3000), ("emps", 1500), ("veh", 1300)])
+def test_generic_propagate_variant_bit_exact(name, N, monkeypatch):
+    """The reference's model shapes (7 x 7 and 9 x 9 x 9 frequency grids, inputs in natural order) run k_propagate instantiations
+    specialised at compile time; PGAS_NO_FAST_VARIANT=1 forces the generic instantiation the other shapes take.  Both must give
+    the oracle's sweep bit for bit."""
+    monkeypatch.setenv("PGAS_NO_FAST_VARIANT", "1")
+    pb, A, S, cm, csmc = _setup(name, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    traj = csmc(SEED, pb.X_true, A, S)
+    trajo, Xo, ANCo, lwo = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
+    X, ANC, LW, _ = csmc.engine.traces()
+    _eq(X, Xo, "state_trace")
+    _eq(ANC[: pb.T - 1], ANCo, "ancestor_trace")
+    _eq(traj, trajo.reshape(traj.shape), "trajectory")
+    info = csmc.engine.launch_info()
+    assert info["JP"] in (8, 12), info   # padded grid extent of the generic instantiations (the fast ones use the exact 7 / 9)
 
 
 def test_sweep_degenerate_weights():
@@ -152,7 +171,7 @@ def test_full_size_properties():
     csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
                                              pb.likelihood_fcn, pb.basis_fcn, keep_logw_trace=True)
     traj = csmc(SEED, pb.X_true, A, S)
-    assert csmc.engine.launch_info()["local_groups"], "N = 2^20 on one device must take the k_step<LOCAL> path the bench measures"
+    assert not csmc.engine.launch_info()["local_groups"], "the bench's default path: k_groups between the steps"
     X, ANC, LW, LT = csmc.engine.traces()
     a = ANC[: pb.T - 1]
     assert int(a.min()) >= 0 and int(a.max()) < N
@@ -212,8 +231,8 @@ def test_full_size_properties_m729(name):
 
 
 def test_two_million_particles_group_path():
-    """N = 2^21 on one device (2048 segments, 32 groups): beyond the window of k_step<LOCAL>, the sweep runs k_groups between the
-    steps -- the path every rank of a sharded sweep takes.  Three steps against the oracle, bit for bit."""
+    """N = 2^21 on one device (2048 segments, 32 groups: the window of a workgroup no longer covers the device).
+    Three steps against the oracle, bit for bit."""
     T = 4
     pb = experiments.smo_pgas(T=T)
     N = 1 << 21

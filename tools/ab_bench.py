@@ -20,6 +20,10 @@ res = {v[0]: [] for v in variants}
 for r in range(rounds):
     for name, path, extra in variants:
         env = dict(os.environ)
+        for tok in [e for e in extra if "=" in e and not e.startswith("-")]:   # NAME=value tokens are environment settings
+            k, v = tok.split("=", 1)
+            env[k] = v
+        extra = [e for e in extra if not ("=" in e and not e.startswith("-"))]
         if path != "-":
             env["PGAS_HIP_LIB"] = os.path.join(root, path)
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-steps", "0", "--steps", "6"] + extra, env=env, capture_output=True, text=True)
