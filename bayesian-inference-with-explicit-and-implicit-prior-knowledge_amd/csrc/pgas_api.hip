@@ -192,7 +192,7 @@ struct pgas_ctx {
     int var_P = 0;              // particles per basis pass of the k_propagate variant
     unsigned launch_tag = 0;    // unique id per k_step launch (hand-off word tag)
     int force_slow = 0;         // 1: never let k_step scan the groups itself (test hook for the k_groups path taken when N > 2^20 per device)
-    int no_tail_groups = 0;     // PGAS_OPT_NO_TAIL_GROUPS: 1 = k_groups launches between the steps also on a single device (test / A-B knob)
+    int tail_groups = 0;        // PGAS_OPT_TAIL_GROUPS: 1 = group scans in k_step's tail instead of k_groups launches (single device; slower, kept as an experiment)
     int ev_stride = 8;          // PGAS_OPT_EVENT_STRIDE: k_propagate launches per event that gates the weight recursion
     int local_groups = 0;       // PGAS_OPT_LOCAL_GROUPS: 1 = k_step<LOCAL> where it applies
     int overlap = 1;            // 1: run the weight recursion on an internal stream concurrently with k_propagate
@@ -491,8 +491,11 @@ static int launch_count(pgas_ctx* c, const ScanBufs& sb, int parity, int what, d
 // issue than the extra tiny launch costs latency).  PGAS_OPT_LOCAL_GROUPS selects it.
 static bool sweep_is_local(const pgas_ctx* c) { return c->local_groups && c->world == 1 && !c->sharded && c->md.nseg_g <= PG_LOCAL_NSEG && !c->force_slow; }
 
-// single device: the group scans ride in k_step's tail (no k_groups launch between the steps); sharded: they need the all-gather first
-static bool sweep_tail_groups(const pgas_ctx* c) { return !c->sharded && c->world == 1 && !c->no_tail_groups; }
+// PGAS_OPT_TAIL_GROUPS (single device only; sharded sweeps need the all-gather first): the group scans ride in k_step's tail, done by
+// the workgroup that completes a group, instead of a k_groups launch between the steps.  Correct and bit-identical, but measured
+// SLOWER (88.5 against 84.9 ms per sweep at N = 2^20: the write-through stores, the drain and the returning atomic at the end of
+// every workgroup cost more than the ~4 us launch they replace), so it is off by default and kept as an experiment.
+static bool sweep_tail_groups(const pgas_ctx* c) { return !c->sharded && c->world == 1 && c->tail_groups; }
 
 // launch t in [1, T] of the sweep: resamples step t-1 (t > 1), scans step t (t < T)
 static int launch_step(pgas_ctx* c, int t, uint64_t seed, bool local, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
@@ -796,8 +799,8 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         c->force_slow = value ? 1 : 0;
         return PGAS_OK;
     }
-    if (option == PGAS_OPT_NO_TAIL_GROUPS) {
-        c->no_tail_groups = value ? 1 : 0;
+    if (option == PGAS_OPT_TAIL_GROUPS) {
+        c->tail_groups = value ? 1 : 0;
         return PGAS_OK;
     }
     if (option == PGAS_OPT_EVENT_STRIDE) {

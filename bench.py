@@ -218,7 +218,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=20, help="steps of the CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--chunk", type=int, default=-1, help="time steps per k_propagate launch (engine default if < 0)")
-    ap.add_argument("--no-tail-groups", action="store_true", help="k_groups as its own launch between the steps instead of in k_step's tail")
+    ap.add_argument("--tail-groups", action="store_true", help="group scans in k_step's tail (in-launch hand-off) instead of k_groups launches between the steps")
     ap.add_argument("--local-groups", action="store_true", help="k_step<LOCAL>: every workgroup scans all groups itself instead of a k_groups launch between the steps")
     ap.add_argument("--event-stride", type=int, default=-1, help="k_propagate launches per gating event (engine default if < 0)")
     ap.add_argument("--no-overlap", action="store_true", help="run the weight recursion on the caller's stream (no concurrency)")
@@ -297,8 +297,8 @@ def main():
         eng.set_option(1, args.chunk)      # PGAS_OPT_PROPAGATE_CHUNK
     if args.local_groups:
         eng.set_option(7, 1)               # PGAS_OPT_LOCAL_GROUPS
-    if args.no_tail_groups:
-        eng.set_option(9, 1)               # PGAS_OPT_NO_TAIL_GROUPS
+    if args.tail_groups:
+        eng.set_option(9, 1)               # PGAS_OPT_TAIL_GROUPS
     if args.event_stride > 0:
         eng.set_option(8, args.event_stride)   # PGAS_OPT_EVENT_STRIDE
     if args.no_overlap:

@@ -82,6 +82,8 @@ def test_basis_init_step_bit_exact(name, N):
     ("smo", 5000, {7: 1}),            # PGAS_OPT_LOCAL_GROUPS: k_step<LOCAL>, every workgroup scans all groups itself
     ("smo", 70000, {7: 1, 1: 7}),     # ... with k_propagate launched in chunks of 7 time steps
     ("smo", 1 << 17, {7: 1}),         # ... two groups
+    ("smo", 1 << 17, {9: 1}),         # PGAS_OPT_TAIL_GROUPS: group scans handed to the last-arriving workgroup inside k_step
+    ("smo", 70000, {9: 1}),           # ... ragged last group
     ("toy", 1500, {1: 1}),            # PGAS_OPT_PROPAGATE_CHUNK = 1: one k_propagate launch per step
 ])
 def test_sweep_bit_exact(name, N, opts):
