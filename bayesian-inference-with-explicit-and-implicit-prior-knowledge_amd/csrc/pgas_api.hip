@@ -22,6 +22,9 @@
 #ifndef PG_W28
 #define PG_W28 2
 #endif
+#ifndef PG_PPT3
+#define PG_PPT3 8   // particles per thread of the 3-D, nx = 2 variants (EMPS / Vehicle M = 729)
+#endif
 #ifndef PG_PPT27
 #define PG_PPT27 8   // particles per thread of that variant (two segments per workgroup: the whole grid is resident at once)
 #endif
@@ -29,7 +32,7 @@
 #define PG_P27 2   // particles per basis pass of the SingleMassOscillator-shaped FAST variant
 #endif
 #ifndef PG_P3
-#define PG_P3 1   // particles per basis pass of the 3-D variants: 1 keeps k_propagate at 164 VGPRs (3 waves/SIMD; 2 -> 209 VGPRs, 2 waves)
+#define PG_P3 4   // particles per basis pass of the 3-D, nx = 2 variants: every coefficient read from LDS feeds four FMAs (measured EMPS-729 at N = 2^20: P = 1 208, P = 2 158, P = 4 147 us per step)
 #endif
 namespace {
 
@@ -101,23 +104,18 @@ struct Variant {
 
 template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT>
 Variant make_variant() {
-    prop_fn one = nullptr;
-    if constexpr (J0T > 0) one = k_propagate<NX, D, JIN, P, W, J0T, PPT, true>;
+    const prop_fn one = k_propagate<NX, D, JIN, P, W, J0T, PPT, true>;
     return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W, J0T, PPT>, one, k_aux<NX, D, JIN, P>, P, W, PPT};
 }
 
 // (nx, D, padded innermost extent) -> kernel instantiation <NX, D, JIN, P particles per basis pass, W waves/SIMD>
 // `fast`: the model has the shape the FAST instantiations are compiled for (sel[d] == d, jstep == j0 in every dimension);
-// J0 = frequencies of the outermost dimension.  The reference's configurations: SingleMassOscillator 7 x 7, EMPS / Vehicle 9 x 9 x 9.
+// J0 = frequencies of the outermost dimension.  SingleMassOscillator: 7 x 7 (the 729-function bases of EMPS / Vehicle select a ball of
+// the 11 x 11 x 11 frequency grid and take the generic 3-D instantiation, which skips the empty part of every row).
 bool pick_variant(int nx, int D, int jin_needed, bool fast, int J0, Variant* v, int* JP) {
     if (fast && nx == 2 && D == 2 && jin_needed == 7 && J0 == 7) {
         *JP = 7;
         *v = make_variant<2, 2, 7, PG_P27, PG_W28, 7, PG_PPT27>();
-        return true;
-    }
-    if (fast && nx == 2 && D == 3 && jin_needed == 9 && J0 == 9) {
-        *JP = 9;
-        *v = make_variant<2, 3, 9, PG_P3, 2, 9>();
         return true;
     }
     if (D == 1) {
@@ -133,7 +131,7 @@ bool pick_variant(int nx, int D, int jin_needed, bool fast, int J0, Variant* v, 
         else *v = jp == 8 ? make_variant<1, 3, 8, 2, 2>() : jp == 12 ? make_variant<1, 3, 12, 2, 2>() : make_variant<1, 3, 16, 2, 2>();
     } else {
         if (D == 2) *v = jp == 8 ? make_variant<2, 2, 8, 2, PG_W28>() : jp == 12 ? make_variant<2, 2, 12, 2, 2>() : make_variant<2, 2, 16, 2, 2>();
-        else *v = jp == 8 ? make_variant<2, 3, 8, PG_P3, 2>() : jp == 12 ? make_variant<2, 3, 12, PG_P3, 2>() : make_variant<2, 3, 16, PG_P3, 2>();
+        else *v = jp == 8 ? make_variant<2, 3, 8, PG_P3, 2, 0, PG_PPT3>() : jp == 12 ? make_variant<2, 3, 12, PG_P3, 2, 0, PG_PPT3>() : make_variant<2, 3, 16, PG_P3, 2, 0, PG_PPT3>();
     }
     return true;
 }
@@ -162,6 +160,7 @@ struct pgas_ctx {
     double* d_u = nullptr;
     int32_t* d_idx = nullptr;
     int32_t* d_pos = nullptr;
+    uint64_t* d_qdesc = nullptr;   // 3-D bases: packed leading non-zero counts per (a, b) row of the frequency grid
     double* d_m0L0 = nullptr;
     double* d_ref = nullptr;   // nx doubles: ref_t of pgas_step / ref0 of pgas_init_state
     double* d_G = nullptr;
@@ -336,6 +335,21 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
         }
         pos[m] = (int32_t)p;
     }
+    if (d->D == 3 && md.J[1] <= 12) {
+        // row descriptors of the frequency grid: 5 bits per (a, b) = leading innermost frequencies in use (0..JP <= 16)
+        std::vector<uint64_t> qd((size_t)md.J[0], 0ull);
+        std::vector<int> ql((size_t)md.J[0] * md.J[1], 0);
+        for (int m = 0; m < d->M; ++m) {
+            const int a = (d->idx[m * 3 + 0] - md.j0[0]) / md.jstep[0], b = (d->idx[m * 3 + 1] - md.j0[1]) / md.jstep[1];
+            const int q = (d->idx[m * 3 + 2] - md.j0[2]) / md.jstep[2] + 1;
+            if (q > ql[(size_t)a * md.J[1] + b]) ql[(size_t)a * md.J[1] + b] = q;
+        }
+        for (int a = 0; a < md.J[0]; ++a)
+            for (int b = 0; b < md.J[1]; ++b) qd[a] |= (uint64_t)ql[(size_t)a * md.J[1] + b] << (5 * b);
+        HIPCHK(c, hipMalloc(&c->d_qdesc, qd.size() * sizeof(uint64_t)));
+        HIPCHK(c, hipMemcpy(c->d_qdesc, qd.data(), qd.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        md.qdesc = c->d_qdesc;
+    }
     c->gtotal = gsize * d->nx;
     HIPCHK(c, hipMalloc(&c->d_G, c->gtotal * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->d_pos, d->M * sizeof(int32_t)));
@@ -381,7 +395,7 @@ int pgas_create(const pgas_model_desc* desc, pgas_ctx** out) {
 void pgas_destroy(pgas_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
-    hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_m0L0); hipFree(c->d_ref);
+    hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_qdesc); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
     hipFree(c->segk_g[0]); hipFree(c->segk_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
     hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail); hipFree(c->ws_partial); hipFree(c->d_sync);
@@ -582,7 +596,12 @@ static int ensure_traces(pgas_ctx* c) {
 static int launch_propagate(pgas_ctx* c, uint64_t seed, int t0, int t1, const double* ref_dev, hipStream_t st, bool timed) {
     const int spw = c->var.PPT / PG_PPT;   // segments per k_propagate workgroup
     const dim3 grid((c->md.nseg + spw - 1) / spw), blk(PG_BLK);
-    const size_t lds = c->overlap ? c->prop_lds : 0;
+    size_t lds = c->overlap ? c->prop_lds : 0;
+    if (c->md.D == 3) {   // the LDS copy of the coefficient tensor (k_propagate, 3-D variants)
+        const size_t need = (size_t)c->gtotal * sizeof(double);
+        if (need > 64 * 1024) FAIL(c, PGAS_E_ARG, "k_propagate: coefficient tensor of %zu bytes does not fit the LDS budget", need);
+        lds = lds > need ? lds : need;
+    }
     const prop_fn prop = (t1 == t0 + 1 && c->var.prop_one) ? c->var.prop_one : c->var.prop;
     if (timed) {
         while ((int)c->evp.size() < c->evp_used + 2) {
@@ -748,7 +767,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     } else {
         // default chunk, measured (tools/overlap_exp.sh, tools/config_times.py): one step per k_propagate launch for the cheap 1-D / 2-D
         // bases, 16 for the 3-D bases whose k_propagate launches are ten times longer than a k_step launch
-        const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? (md.D >= 3 ? 16 : 1) : T);
+        const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 1 : T);
         c->last_chunk = chunk;
         rc = run_time_loop(c, seed, ref_dev, chunk, st);
         if (rc) return rc;
@@ -1127,7 +1146,7 @@ int pgas_shard_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* 
     if (T == 1) {
         HIPCHK(c, hipMemsetAsync(c->logw_last, 0, md.N * sizeof(double), st));
     } else {
-        const int chunk = propagate_chunk > 0 ? propagate_chunk : (c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? (md.D >= 3 ? 16 : 1) : T));
+        const int chunk = propagate_chunk > 0 ? propagate_chunk : (c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 1 : T));
         c->last_chunk = chunk;
         rc = run_time_loop(c, seed, ref_dev, chunk, st);
         if (rc) return rc;

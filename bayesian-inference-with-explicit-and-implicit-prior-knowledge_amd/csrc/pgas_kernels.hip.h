@@ -60,6 +60,10 @@ struct DevModel {
     int32_t nseg_g;   // global segment count
     const double* y;  // device (T,ny)
     const double* u;  // device (T,nu)
+    const uint64_t* qdesc;  // device (J[0]) or NULL, 3-D bases: per outermost frequency a, the count of leading innermost frequencies
+                            // that carry a basis function in row (a, b), 5 bits per b (J[1] <= 12) -- the selected index sets are
+                            // balls, not boxes (src/BasisFunctions.py:33-57), so about half of the dense grid is zeros the contraction
+                            // can skip (exact: adding 0 * s changes nothing)
 };
 
 struct TransParams {   // transition parameters, by value
@@ -449,6 +453,7 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
 #pragma unroll
                     for (int k = 0; k < NX; ++k) mid[p][k] = 0.0;
                 }
+                const uint64_t desc = md.qdesc ? md.qdesc[a] : 0ull;   // one scalar load per outermost frequency
                 for (int b = 0; b < J1; ++b) {
                     double in[P][NX];
 #pragma unroll
@@ -456,13 +461,19 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
 #pragma unroll
                         for (int k = 0; k < NX; ++k) in[p][k] = 0.0;
                     const double* __restrict__ Gab = G + ((size_t)a * J1 + b) * JIN * NX;
+                    const int qn = md.qdesc ? (int)((desc >> (5 * b)) & 31u) : JIN;   // uniform: the row's coefficients beyond qn are zeros
 #pragma unroll
-                    for (int q = 0; q < JIN; ++q) {
+                    for (int q0 = 0; q0 < JIN; q0 += 4) {
+                        if (q0 < qn) {   // uniform branch per chunk of four frequencies
 #pragma unroll
-                        for (int k = 0; k < NX; ++k) {
-                            const double g = Gab[q * NX + k];
+                            for (int q = q0; q < (q0 + 4 < JIN ? q0 + 4 : JIN); ++q) {
 #pragma unroll
-                            for (int p = 0; p < P; ++p) in[p][k] = PGAS_FMA(g, tab[p][q], in[p][k]);
+                                for (int k = 0; k < NX; ++k) {
+                                    const double g = Gab[q * NX + k];
+#pragma unroll
+                                    for (int p = 0; p < P; ++p) in[p][k] = PGAS_FMA(g, tab[p][q], in[p][k]);
+                                }
+                            }
                         }
                     }
 #pragma unroll
@@ -832,12 +843,12 @@ __global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, TransParams tp, i
 // log-densities, new state): the FAST k_propagate walks its PG_PPT particles group by group so that only one group's
 // intermediates are live at a time (the all-at-once form needs ~165 VGPRs, this one fits four waves per SIMD).
 template <int NX, int D, int JIN, int P, int J0T>
-__device__ __forceinline__ void propagate_group(const DevModel& md, const TransParams& tp, int t, uint64_t seed, const double (&rf)[NX],
+__device__ __forceinline__ void propagate_group(const DevModel& md, const TransParams& tp, const double* G, int t, uint64_t seed, const double (&rf)[NX],
                                                 const double* __restrict__ yt, const double* __restrict__ ut, int seg, int r0,
                                                 const double (&xin)[P][NX], double (&xn)[P][NX], double (&la)[P], double (&h)[P], double (&ln)[P]) {
     const int tid = threadIdx.x;
     double aux[P][NX];
-    eval_mean<NX, D, JIN, P, J0T>(md, tp.G, ut, xin, aux);
+    eval_mean<NX, D, JIN, P, J0T>(md, G, ut, xin, aux);
     double z0[P], z1[P];
     {
         pgas_u32x4 w[P];
@@ -882,10 +893,9 @@ __device__ __forceinline__ void propagate_group(const DevModel& md, const TransP
     }
 }
 
-// PPT = particles per thread.  The generic instantiations take PG_PPT = 4 (one segment per workgroup, grid = nseg).  The FAST ones
-// take 8 (two segments per workgroup, grid = ceil(nseg / 2)): at ~156 VGPRs three waves fit a SIMD, so 1024 four-wave workgroups
-// need 1.33 rounds and the last third of the grid runs alone, one wave per SIMD, exposing every dependent-issue latency --
-// the kernel took 25.6 us for 16 us of vector issue.  512 workgroups of twice the work are resident all at once.
+// PPT = particles per thread: PPT / 4 segments per workgroup, grid = ceil(nseg / (PPT / 4)).  A thread walks its particles in
+// groups of P (propagate_group).  Measured on the SingleMassOscillator sweep: PPT = 8 (512 workgroups at N = 2^20, all resident
+// at once) beats 4 by 6-9 % when the weight recursion runs beside it.
 // ONE = the launch covers exactly one time step (t1 == t0 + 1; what the sweep uses for the cheap bases): a group's state is then
 // loaded right before its pass instead of being held for the whole launch (8 particles x 2 doubles = 32 VGPRs less).
 template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT, bool ONE = false>
@@ -895,7 +905,18 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
                                                           double* __restrict__ ln_buf) {
     const int tid = threadIdx.x;
     const size_t row = (size_t)md.N * NX, np = (size_t)md.nseg * PGAS_SEG;
-    if constexpr (J0T > 0) {
+    // 3-D bases: the coefficient tensor (J0 x J1 x JIN x NX doubles, 23 KB for the 729-function bases) is copied to LDS once per launch
+    // and read from there with wave-uniform (broadcast) addresses: per row of the frequency grid the scalar-load path would stall
+    // on a fresh s_load (24 coefficients for 48 FMAs), LDS reads pipeline behind the FMAs.
+    const double* Guse = tp.G;
+    if constexpr (D == 3) {
+        extern __shared__ __attribute__((aligned(16))) double pg_g_lds[];
+        const int gtot = md.J[0] * md.J[1] * JIN * NX;
+        for (int i = tid; i < gtot; i += PG_BLK) pg_g_lds[i] = tp.G[i];
+        __syncthreads();
+        Guse = pg_g_lds;
+    }
+    {
         static_assert(PPT % PG_PPT == 0 && PPT % P == 0, "whole segments per workgroup, whole groups per thread");
         const int seg0 = blockIdx.x * (PPT / PG_PPT);
         // particle r of this thread: segment seg0 + r / 4, row (r % 4) * 256 + tid inside it (the layout every other kernel uses)
@@ -947,7 +968,7 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
 #pragma unroll
                     for (int p = 0; p < P; ++p) load_state(rn + p, xnext[p]);
                 }
-                propagate_group<NX, D, JIN, P, J0T>(md, tp, t, seed, rf, yt, ut, seg0 + r0 / PG_PPT, r0 % PG_PPT, xin, xn, la, h, ln);
+                propagate_group<NX, D, JIN, P, J0T>(md, tp, Guse, t, seed, rf, yt, ut, seg0 + r0 / PG_PPT, r0 % PG_PPT, xin, xn, la, h, ln);
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const size_t pi = particle(r0 + p);   // la / h / ln are padded to nseg*SEG
@@ -971,25 +992,6 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
                         for (int k = 0; k < NX; ++k) xv[r0 + p][k] = xn[p][k];
                     }
                 }
-            }
-        }
-    } else {
-        const int seg = blockIdx.x;
-        double xv[PG_PPT][NX];
-        load_particles<NX>(md, x_trace + (size_t)(t0 - 1) * row, seg, xv);
-        for (int t = t0; t < t1; ++t) {
-            const double* __restrict__ yt = md.y + (size_t)t * md.ny;
-            double xn[PG_PPT][NX], la[PG_PPT], h[PG_PPT], aux[PG_PPT][NX];
-            propagate_particles<NX, D, JIN, P, J0T>(md, tp, t, seed, ref + (size_t)t * NX, seg, xv, xn, la, h, aux);
-            store_particles<NX>(md, x_trace + (size_t)t * row, seg, xn);
-#pragma unroll
-            for (int r = 0; r < PG_PPT; ++r) {
-                const size_t pi = (size_t)seg * PGAS_SEG + r * PG_BLK + tid;  // buffers are padded to nseg*SEG
-                la_buf[(size_t)t * np + pi] = la[r];
-                h_buf[(size_t)t * np + pi] = h[r];
-                ln_buf[(size_t)t * np + pi] = loglik<NX>(md, yt, xn[r]);
-#pragma unroll
-                for (int k = 0; k < NX; ++k) xv[r][k] = xn[r][k];
             }
         }
     }

@@ -23,7 +23,7 @@ for name, mk in [c for c in cfgs if os.environ.get("ONLY", "") in c[0]]:
         t0 = time.perf_counter(); csmc(2 + k, pb.X_true, A, S); torch.cuda.synchronize(); dt = min(dt, time.perf_counter() - t0)
     n, ms, pn, pm = csmc.engine.profile()
     print(f"{name:24s} T={pb.T:4d}: {1e3*dt:8.2f} ms/sweep = {1e6*dt/(pb.T-1):7.2f} us/step, {N*(pb.T-1)/dt:.3e} particle-steps/s; "
-          f"k_resample {1e3*ms/max(n,1):6.2f} us/launch, k_propagate {1e3*pm/max(pn,1):7.2f} us/launch")
+          f"k_step {1e3*ms/max(n,1):6.2f} us/launch, k_propagate {1e3*pm/max(pn,1):7.2f} us/launch")
     csmc.engine.close()
     del csmc
     torch.cuda.empty_cache()
