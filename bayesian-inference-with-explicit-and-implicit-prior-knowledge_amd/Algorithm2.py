@@ -27,7 +27,11 @@ class Algorithm2:
         c = self.cSMC
         out = []
         for i in range(c.N_int):
-            basis = torch.stack([c.basis_fcn[i](state_traj[t:t + 1], c.inputs[t]).reshape(-1) for t in range(self.N_steps)])   # (T,M)
+            bf = c.basis_fcn[i]
+            if hasattr(bf, "trajectory"):      # descriptors evaluate the whole trajectory in one batched call, row t with inputs[t]
+                basis = bf.trajectory(state_traj, c.inputs.reshape(self.N_steps, -1))
+            else:                              # arbitrary user callables keep the reference's per-step call
+                basis = torch.stack([bf(state_traj[t:t + 1], c.inputs[t]).reshape(-1) for t in range(self.N_steps)])   # (T,M)
             xi = int_var_traj[i].reshape(-1)
             out.append((basis.T @ xi, basis.T @ basis, (xi * xi).sum(), torch.tensor(float(self.N_steps), dtype=torch.float64, device=c.device)))
         return out

@@ -202,6 +202,9 @@ struct pgas_ctx {
     hipEvent_t ev_start = nullptr, ev_done = nullptr;
     // suff-stat scratch
     double* d_phi = nullptr;
+    double* d_syrk_ws = nullptr;   // split-K partial slabs of Z^T Z (pgas_suffstats)
+    size_t syrk_ws_bytes = 0;
+    int syrk_splits = 0;           // 0 = automatic
     // optional per-launch timing of the dominant kernel (pgas_set_profiling)
     int profiling = 0;
     int prof_stride = 16;       // every prof_stride-th launch carries start/stop events (hipExtLaunchKernelGGL: the dispatch's own timestamps)
@@ -398,7 +401,7 @@ void pgas_destroy(pgas_ctx* c) {
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_qdesc); hipFree(c->d_m0L0); hipFree(c->d_ref);
     hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
     hipFree(c->segk_g[0]); hipFree(c->segk_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
-    hipFree(c->d_phi); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail); hipFree(c->ws_partial); hipFree(c->d_sync);
+    hipFree(c->d_phi); hipFree(c->d_syrk_ws); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail); hipFree(c->ws_partial); hipFree(c->d_sync);
     if (c->comm && rccl().destroy) rccl().destroy(c->comm);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (hipEvent_t e : c->evp) hipEventDestroy(e);
@@ -625,7 +628,9 @@ static int ensure_side_stream(pgas_ctx* c, int nchunk) {
         int lo = 0, hi = 0;
         HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
         // measured (tools/overlap_exp.sh): the chain stream at LOW priority and one-step k_propagate launches overlap best
-        HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, lo));
+        const char* pe = getenv("PGAS_CHAIN_PRIO");   // development knob: 1 = highest, 2 = default priority
+        const int pr = pe && pe[0] == '1' ? hi : (pe && pe[0] == '2' ? 0 : lo);
+        HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, pr));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
     }
@@ -820,6 +825,11 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
     }
     if (option == PGAS_OPT_TAIL_GROUPS) {
         c->tail_groups = value ? 1 : 0;
+        return PGAS_OK;
+    }
+    if (option == PGAS_OPT_SYRK_SPLITS) {
+        if (value < 0 || value > 32) FAIL(c, PGAS_E_ARG, "pgas_set_option: SYRK splits must be 0 (automatic) .. 32");
+        c->syrk_splits = (int)value;
         return PGAS_OK;
     }
     if (option == PGAS_OPT_EVENT_STRIDE) {
@@ -1217,17 +1227,27 @@ int pgas_suffstats(pgas_ctx* c, const double* traj_dev, double* T0_dev, double* 
     DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
     const int R = md.T - 1;                         // rows: t = 0..T-2   (traj[:-1], inputs[:-1]; Q3)
-    const int Mp = (md.M + 15) / 16 * 16;           // padded to the MFMA tile
-    const int Rp = (R + 3) / 4 * 4;
+    const int Mp = (md.M + md.nx + SY_BM - 1) / SY_BM * SY_BM;   // [Phi | X+] padded to the 64-wide block
+    const int Rp = (R + SY_KB - 1) / SY_KB * SY_KB;
+    const int nb = Mp / SY_BM, ntri = nb * (nb + 1) / 2, nkb = Rp / SY_KB;
+    int S = c->syrk_splits > 0 ? c->syrk_splits : 1024 / ntri;   // automatic: the largest split that keeps ntri x S within four workgroups per CU
+    S = std::max(1, std::min(std::min(S, 32), nkb));
+    const int kb_per_split = (nkb + S - 1) / S;
+    S = (nkb + kb_per_split - 1) / kb_per_split;
     if (!c->d_phi) HIPCHK(c, hipMalloc(&c->d_phi, (size_t)Rp * Mp * sizeof(double)));
-    HIPCHK(c, hipMemsetAsync(c->d_phi, 0, (size_t)Rp * Mp * sizeof(double), st));
-    hipLaunchKernelGGL(md.nx == 1 ? k_traj_basis<1> : k_traj_basis<2>, dim3((R + 63) / 64), dim3(64), 0, st, md, c->d_idx, traj_dev, R, Mp, c->d_phi);
+    const size_t ws_need = (size_t)S * ntri * SY_BM * SY_BM * sizeof(double);
+    if (ws_need > c->syrk_ws_bytes) {
+        if (c->d_syrk_ws) HIPCHK(c, hipFree(c->d_syrk_ws));
+        c->d_syrk_ws = nullptr; c->syrk_ws_bytes = 0;
+        HIPCHK(c, hipMalloc(&c->d_syrk_ws, ws_need));
+        c->syrk_ws_bytes = ws_need;
+    }
+    hipLaunchKernelGGL(md.nx == 1 ? k_traj_basis<1> : k_traj_basis<2>, dim3(Rp / SY_RB), dim3(256), 0, st, md, c->d_idx, traj_dev, R, Rp, Mp, c->d_phi);
     KCHK(c, "k_traj_basis");
-    const int tiles = Mp / 16;
-    hipLaunchKernelGGL(k_syrk_mfma, dim3(tiles, tiles), dim3(64), 0, st, c->d_phi, Rp, Mp, md.M, T1_dev);
-    KCHK(c, "k_syrk_mfma");
-    hipLaunchKernelGGL(k_t0t2, dim3((md.M + 63) / 64 + 1), dim3(64), 0, st, c->d_phi, traj_dev, R, Mp, md.M, md.nx, T0_dev, T2_dev);
-    KCHK(c, "k_t0t2");
+    hipLaunchKernelGGL(k_syrk_lds, dim3(ntri, S), dim3(256), 0, st, c->d_phi, Rp, Mp, kb_per_split, c->d_syrk_ws);
+    KCHK(c, "k_syrk_lds");
+    hipLaunchKernelGGL(k_syrk_reduce, dim3(ntri, SY_BM * SY_BM / 256), dim3(256), 0, st, c->d_syrk_ws, ntri, S, md.M, md.nx, T0_dev, T1_dev, T2_dev);
+    KCHK(c, "k_syrk_reduce");
     return PGAS_OK;
 }
 

@@ -69,22 +69,29 @@ class BasisMap:
             v = np.concatenate([v, np.atleast_1d(np.asarray(input, dtype=np.float64)).reshape(-1)])
         return self.basis(v[self.sel] / self.div)
 
-    def batch(self, state, input=None):
+    def trajectory(self, states, inputs=None):
+        """Basis along a trajectory in one call: states (T, n_x), inputs (T, n_u) -- row t is evaluated with inputs[t] -> (T, M)."""
+        return self.batch(states, inputs, per_row=True)
+
+    def batch(self, state, input=None, per_row=False):
         """Batched evaluation for the marginalised family (Algorithm1/2/3): state (N, n_x) NumPy array or torch tensor, input (n_u,)
-        or None -> (N, M) of the same kind.  phi = prod_d sqrt(1/L_d) sin(pi j_d (v_d/div_d - center_d + L_d) / size_d)
+        (one input for all rows; per_row: (N, n_u), one per row) or None -> (N, M) of the same kind.  phi = prod_d sqrt(1/L_d) sin(pi j_d (v_d/div_d - center_d + L_d) / size_d)
         (src/BasisFunctions.py:77-80)."""
         b = self.basis
         if isinstance(state, np.ndarray):
             v = state.reshape(state.shape[0], -1)
             if input is not None and np.size(input):
-                v = np.concatenate([v, np.broadcast_to(np.asarray(input, dtype=np.float64).reshape(1, -1), (v.shape[0], np.size(input)))], axis=1)
+                inp = np.asarray(input, dtype=np.float64)
+                rows = inp.reshape(v.shape[0], -1) if inp.ndim == 2 and inp.shape[0] == v.shape[0] and per_row else np.broadcast_to(inp.reshape(1, -1), (v.shape[0], inp.size))
+                v = np.concatenate([v, rows], axis=1)
             ang = np.pi * b.indices[None, :, :] * ((v[:, self.sel] / self.div - b.center + b.L) / b.size)[:, None, :]
             return np.prod(np.sqrt(1.0 / b.L) * np.sin(ang), axis=2)
         import torch
 
         v = state.reshape(state.shape[0], -1)
         if input is not None and input.numel():
-            v = torch.cat([v, input.reshape(1, -1).expand(v.shape[0], -1)], dim=1)
+            rows = input.reshape(v.shape[0], -1) if per_row else input.reshape(1, -1).expand(v.shape[0], -1)
+            v = torch.cat([v, rows], dim=1)
         key = v.device
         if getattr(self, "_tcache", None) is None or self._tcache[0] != key:
             tt = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=v.device)  # noqa: E731

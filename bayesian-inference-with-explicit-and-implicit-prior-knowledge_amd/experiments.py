@@ -212,7 +212,7 @@ class MarginalProblem:
 
     def basis_fcn(self):
         """basis_fcn[i](state (N,n_x), input) -> (N,M); entries of `basis` are BasisMap descriptors or plain batched callables."""
-        return [(lambda state, input, b=b: b.batch(state, input)) if hasattr(b, "batch") else b for b in self.basis]
+        return [_BatchedBasis(b) if hasattr(b, "batch") else b for b in self.basis]
 
 
 def smo_marginal(T=750, seed=12345678):
@@ -266,6 +266,19 @@ def toy_marginal(T=40, seed=12345678):
                            [np.array([10 * np.sinc(0.0)])], [np.diag([4.0])], [pt.GP_prior], [pt.basis_fcn], 1.0, model, X, [fx_true])
 
 
+class _BatchedBasis:
+    """A descriptor as the batched callable Algorithm1/2/3 expect, keeping its one-call trajectory evaluation."""
+
+    def __init__(self, b):
+        self.b = b
+
+    def __call__(self, state, input):
+        return self.b.batch(state, input)
+
+    def trajectory(self, states, inputs):
+        return self.b.trajectory(states, inputs)
+
+
 class _SlipAngleBasis:
     """basis_fcn_f / basis_fcn_r of src/Vehicle.py:146-153: the 1-D Hilbert basis evaluated at the front / rear tyre side-slip angle
     (f_alpha, :51-58).  Batched, NumPy or torch."""
@@ -275,12 +288,15 @@ class _SlipAngleBasis:
 
     def alpha(self, state, input):
         xp = np if isinstance(state, np.ndarray) else __import__("torch")
-        if self.rear:
-            return -xp.arctan((state[:, 1] - state[:, 0] * self.l_r) / input[1])
-        return input[0] - xp.arctan((state[:, 1] + state[:, 0] * self.l_f) / input[1])
+        if self.rear:                                   # input (n_u,) or, along a trajectory, (T, n_u)
+            return -xp.arctan((state[:, 1] - state[:, 0] * self.l_r) / input[..., 1])
+        return input[..., 0] - xp.arctan((state[:, 1] + state[:, 0] * self.l_f) / input[..., 1])
 
     def batch(self, state, input):
         return self.map.batch(self.alpha(state, input).reshape(-1, 1), None)
+
+    def trajectory(self, states, inputs):
+        return self.batch(states, inputs)
 
     def __call__(self, state, input):
         return self.batch(state, input)

@@ -31,6 +31,22 @@ def test_suffstats_match_numpy(maker):
     assert np.allclose(T1.cpu().numpy(), T1.cpu().numpy().T, rtol=0, atol=1e-13 * np.abs(r1).max())
 
 
+@pytest.mark.parametrize("maker,splits", [(lambda: experiments.emps_pgas(T=2000), 0), (lambda: experiments.emps_pgas(T=2000), 3),
+                                          (lambda: experiments.smo_pgas(T=2000), 0), (lambda: experiments.smo_pgas(T=2000), 1)])
+def test_suffstats_full_size(maker, splits):
+    """T = 2000 rows, M = 729 / 41 columns: the LDS-staged split SYRK against numpy's Phi^T Phi, for the automatic and a forced row split."""
+    pb = maker()
+    pg = pgas_amd.PGAS(256, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior, pb.basis_fcn)
+    pg.cSMC.engine.set_option(10, splits)
+    T0, T1, T2, T3 = pg.cSMC.engine.suffstats(pb.X_true)
+    r0, r1, r2, r3 = pgas_numpy.suff_stats(pb.X_true, _phi_numpy(pb))
+    for g, r, nm in ((T0, r0, "T0"), (T1, r1, "T1"), (T2, r2, "T2")):
+        g = g.cpu().numpy()
+        assert g.shape == r.shape
+        assert np.abs(g - r).max() <= RTOL * np.abs(r).max() * pb.T, f"{nm}: max |d| = {np.abs(g - r).max():.3e}"
+    assert torch.equal(T1, T1.T) and T3 == r3
+
+
 def test_sample_params_matches_numpy_on_same_draws():
     pb = experiments.smo_pgas(T=200)
     pg = pgas_amd.PGAS(256, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior, pb.basis_fcn)

@@ -100,3 +100,19 @@ def test_restatement_matches_committed_vectors(name):
     for i in range(len(pb.basis)):
         assert np.allclose(o1[1][i][-1].reshape(-1), g["alg1_int_var_last"][i], rtol=1e-9, atol=1e-12)
         assert np.allclose(np.diag(o1[2][i][1][-1]), g["alg1_T1_trace_diag_last"][i], rtol=1e-9, atol=1e-13)
+
+
+@pytest.mark.parametrize("name", ["smo", "vehicle", "emps", "toy"])
+def test_trajectory_basis_equals_per_step_calls(name):
+    """Algorithm2's trajectory statistics evaluate the basis for all T rows in one call (row t with inputs[t]); that call must equal
+    the reference's per-step calls (src/Algorithm2.py:81-93)."""
+    mk = {"smo": lambda: experiments.smo_marginal(T=30), "vehicle": lambda: experiments.vehicle_marginal(T=30),
+          "emps": lambda: experiments.emps_marginal(T=30), "toy": lambda: experiments.toy_marginal(T=20)}[name]
+    pb = mk()
+    X = np.asarray(pb.X_true, dtype=np.float64).reshape(pb.T, -1)
+    U = np.asarray(pb.inputs, dtype=np.float64).reshape(pb.T, -1)
+    for bf in pb.basis_fcn():
+        assert hasattr(bf, "trajectory")
+        whole = bf.trajectory(X, U)
+        steps = np.vstack([bf(X[t:t + 1], U[t]) for t in range(pb.T)])
+        assert whole.shape == steps.shape and np.array_equal(whole, steps)
