@@ -81,16 +81,23 @@ class PGAS:
         dev = self.cSMC.device
         f = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)  # noqa: E731
         self.GP_prior = (f(GP_prior[0]), f(GP_prior[1]), f(np.atleast_2d(GP_prior[2])), float(GP_prior[3]))
+        self._df_vec = None
+        self._eye = (torch.eye(self.cSMC.engine.M, dtype=torch.float64, device=dev), torch.eye(self.cSMC.engine.nx, dtype=torch.float64, device=dev))
 
     # ---- src/PGAS.py:288-343 ------------------------------------------------------------------
     def param_draws(self, key):
-        """The random numbers sample_params consumes: chi^2(df - i) (:323-327), tril normals (:328), A normals (:338)."""
-        nx, M = self.cSMC.engine.nx, self.cSMC.engine.M
+        """The random numbers sample_params consumes: chi^2(df - i) (:323-327), tril normals (:328), A normals (:338) -- drawn on the
+        device from the Philox streams of the three sub-keys (k_rng_chi2, k_rng_normal); nothing crosses PCIe."""
+        eng = self.cSMC.engine
+        nx, M = eng.nx, eng.M
         df = self.GP_prior[3] + (self.N_steps - 1)
         key_A, key_S = prng.split(key, 2)
         key_chi, key_norm = prng.split(key_S, 2)
-        return dict(chi2=prng.chisquare(key_chi, df - np.arange(nx)), normals_T=prng.normal(key_norm, (nx, nx)),
-                    normals_A=prng.normal(key_A, (nx, M)))
+        if self._df_vec is None or self._df_vec[0] != df:
+            self._df_vec = (df, torch.as_tensor(df - np.arange(nx, dtype=np.float64), device=eng.device))
+        return dict(chi2=eng.rng_chi2(key_chi, prng.STREAM_PARAM_UNIFORM, 0, self._df_vec[1]),
+                    normals_T=eng.rng_normal(key_norm, prng.STREAM_PARAM_NORMAL, 0, nx * nx).reshape(nx, nx),
+                    normals_A=eng.rng_normal(key_A, prng.STREAM_PARAM_NORMAL, 0, nx * M).reshape(nx, M))
 
     def sample_params(self, key, state_trajectory, draws=None):
         """(A (nx,M), S (nx,nx)) ~ p(A, S | trajectory): suff-stats on the engine (fp64 MFMA SYRK),
@@ -100,13 +107,13 @@ class PGAS:
         T0, T1, T2, T3 = eng.suffstats(state_trajectory)                      # :294-303
         e0, e1, e2, e3 = self.GP_prior[0] + T0, self.GP_prior[1] + T1, self.GP_prior[2] + T2, self.GP_prior[3] + T3
         Lc = torch.linalg.cholesky(e1)                                         # BI:35-45
-        sol = torch.cholesky_solve(torch.cat([e0, torch.eye(eng.M, dtype=torch.float64, device=dev)], dim=1), Lc)
+        sol = torch.cholesky_solve(torch.cat([e0, self._eye[0]], dim=1), Lc)
         mean, col_cov = sol[:, : eng.nx].T.contiguous(), sol[:, eng.nx:]
         row_scale = e2 - mean @ e0
         if draws is None:
             draws = self.param_draws(key)
-        g = lambda a: torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)  # noqa: E731
-        eye = torch.eye(eng.nx, dtype=torch.float64, device=dev)
+        g = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)  # noqa: E731
+        eye = self._eye[1]
         L = torch.linalg.solve_triangular(torch.linalg.cholesky(row_scale), eye, upper=False)      # :317-319
         Tm = torch.tril(g(draws["normals_T"]), diagonal=-1) + torch.diag(torch.sqrt(g(draws["chi2"])))  # :327-329
         Cm = L @ Tm                                                            # :332

@@ -39,7 +39,7 @@ EXPORTS = [
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
     "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
-    "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
+    "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_chi2", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)   # pgas_allgather_fn (include/pgas_hip.h)
@@ -124,6 +124,8 @@ def load():
     L.pgas_m_rng_normal.argtypes = [vp, u64, u32, u32, i64, i64, i32, vp, vp]
     L.pgas_m_rng_student_t.restype = C.c_int
     L.pgas_m_rng_student_t.argtypes = [vp, u64, u32, u32, i64, i64, vp, vp, vp]
+    L.pgas_m_rng_chi2.restype = C.c_int
+    L.pgas_m_rng_chi2.argtypes = [vp, u64, u32, u32, i64, i64, vp, vp, vp]
     L.pgas_m_mniw_solve.restype = C.c_int
     L.pgas_m_mniw_solve.argtypes = [vp, i64, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pgas_m_mniw_trisolve.restype = C.c_int
@@ -449,6 +451,19 @@ class Engine:
         """torch view of library-owned device memory."""
         typestr = {torch.float64: "<f8", torch.int64: "<i8", torch.int32: "<i4"}[dtype]
         return torch.as_tensor(_DevView(ptr, shape, typestr, self), device=self.device)
+
+    def rng_normal(self, seed, stream, t, n, ncol=1):
+        """(n, ncol) standard normals of counters (particle 0..n-1, t, stream) -- Philox + Box-Muller on the device (k_rng_normal)."""
+        out = torch.empty((int(n), int(ncol)), dtype=torch.float64, device=self.device)
+        self._chk(self.lib.pgas_m_rng_normal(self._h, int(seed), int(stream), int(t), 0, int(n), int(ncol), out.data_ptr(), self._stream()), "pgas_m_rng_normal")
+        return out
+
+    def rng_chi2(self, seed, stream, t, nu):
+        """chi^2(nu_p) variates for a device vector nu (k_rng_chi2)."""
+        nu = nu.to(device=self.device, dtype=torch.float64).contiguous()
+        out = torch.empty_like(nu)
+        self._chk(self.lib.pgas_m_rng_chi2(self._h, int(seed), int(stream), int(t), 0, nu.numel(), nu.data_ptr(), out.data_ptr(), self._stream()), "pgas_m_rng_chi2")
+        return out
 
     def suffstats(self, traj):
         traj = self._dev(traj, shape=(self.T, self.nx))

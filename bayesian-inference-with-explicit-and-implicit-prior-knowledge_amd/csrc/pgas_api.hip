@@ -1277,6 +1277,16 @@ int pgas_m_rng_student_t(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t
     return PGAS_OK;
 }
 
+int pgas_m_rng_chi2(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu, double* out, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!out || !nu || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_rng_chi2: bad argument");
+    if (n == 0) return PGAS_OK;
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(k_rng_chi2, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, p0, n, nu, out);
+    KCHK(c, "k_rng_chi2");
+    return PGAS_OK;
+}
+
 int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int32_t* anc, const double* P0, const double* P1, const double* T0, const double* T1,
                       const double* R0, const double* R1, const double* phi, double* m, double* cc, double* q, double* logdet, double* Lfac, void* sh) {
     if (!c) return PGAS_E_ARG;

@@ -29,6 +29,14 @@ __global__ __launch_bounds__(256) void k_rng_student_t(uint64_t seed, uint32_t s
     out[p] = pgas_rng_student_t(seed, stream, t, (uint64_t)(p0 + p), nu[p]);
 }
 
+// chi^2(nu_p) = 2 Gamma(nu_p / 2): the Bartlett diagonal of PGAS.sample_params (src/PGAS.py:323-327), drawn where it is consumed
+__global__ __launch_bounds__(256) void k_rng_chi2(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* __restrict__ nu,
+                                                   double* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    out[p] = 2.0 * pgas_rng_gamma(seed, stream, t, (uint64_t)(p0 + p), 0.5 * nu[p]);
+}
+
 #define PG_MN_MAXM 62      // one matrix row per lane plus the two right-hand-side rows; particles per workgroup = blockDim.x / 64
 
 __device__ __forceinline__ double wave_sum_f64(double v) {

@@ -31,6 +31,11 @@ int pgas_m_rng_normal(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t,
 int pgas_m_rng_student_t(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu_dev,
                          double* out_dev, void* stream_handle);
 
+/* chi^2(nu_p) variates, out[p] = 2 Gamma(nu_p / 2) on the counters of particle p0 + p (pgas_rng_gamma, include/pgas_canon.h): the
+ * diagonal of the Bartlett factor in PGAS.sample_params (reference src/PGAS.py:323-327, jax.random.chisquare there). */
+int pgas_m_rng_chi2(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu_dev, double* out_dev,
+                    void* stream_handle);
+
 /* Per particle p, with s = anc[p] (anc NULL: s = p): eta0 = P0 + scale T0[s] (+ R0), eta1 = P1 + scale T1[s] (+ R1)
  * (M <= 62, eta1 symmetric positive definite);
  *   m[p] = eta0^T eta1^-1 phi[p],  c[p] = phi[p]^T eta1^-1 phi[p],  q[p] = eta0^T eta1^-1 eta0,  logdet[p] = log det eta1.

@@ -61,6 +61,8 @@ def lib():
         L.oc_uniform.restype = C.c_double
         L.oc_uniform.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32]
         L.oc_normals.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int, dp]
+        L.oc_chi2.restype = None
+        L.oc_chi2.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, dp, dp]
         L.oc_student_t.restype = None
         L.oc_student_t.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, dp, dp]
         L.oc_gamma.restype = None
@@ -124,6 +126,14 @@ def normals(seed, stream, t, p0, n_particles, n):
     z = np.empty((n_particles, n))
     lib().oc_normals(seed, stream, t, p0, n_particles, n, _dp(z))
     return z
+
+
+def chi2(seed, stream, t, p0, nu):
+    """chi^2(nu_p) on the counters of particle p0 + p (2 x pgas_rng_gamma(nu_p / 2))."""
+    nu = np.ascontiguousarray(nu, dtype=np.float64)
+    out = np.empty_like(nu)
+    lib().oc_chi2(seed, stream, t, p0, nu.size, _dp(nu), _dp(out))
+    return out
 
 
 def student_t(seed, stream, t, p0, nu):

@@ -63,6 +63,10 @@ EXPORT void oc_normals(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, i
     for (int64_t p = 0; p < np; ++p) pgas_rng_normals(seed, stream, t, (uint64_t)(p0 + p), n, z + p * n);
 }
 /* Student-t(nu[p]) variates of particles p0 .. p0+np (marginalised family, BI:104) */
+EXPORT void oc_chi2(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t np, const double* nu, double* out) {
+    for (int64_t p = 0; p < np; ++p) out[p] = 2.0 * pgas_rng_gamma(seed, stream, t, (uint64_t)(p0 + p), 0.5 * nu[p]);
+}
+
 EXPORT void oc_student_t(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t np, const double* nu, double* out) {
     for (int64_t p = 0; p < np; ++p) out[p] = pgas_rng_student_t(seed, stream, t, (uint64_t)(p0 + p), nu[p]);
 }

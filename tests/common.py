@@ -99,3 +99,14 @@ def marginal_oracle(problem, N, kind="Algorithm1"):
     if kind == "Algorithm1":
         return mo.Algorithm1(forgetting_factor=problem.forgetting_factor, **args)
     return mo.Algorithm3(**args)
+
+
+def host_param_draws(key, nx, M, df):
+    """The numbers PGAS.param_draws generates on the device, recomputed on the host from the same key by the canonical C oracle:
+    split(key) -> (key_A, key_S), split(key_S) -> (key_chi, key_norm); chi^2(df - i), (nx, nx) and (nx, M) standard normals."""
+    from pgas_amd import random as prng
+    key_A, key_S = prng.split(key, 2)
+    key_chi, key_norm = prng.split(key_S, 2)
+    return dict(chi2=canon.chi2(key_chi, prng.STREAM_PARAM_UNIFORM, 0, 0, df - np.arange(nx, dtype=np.float64)),
+                normals_T=canon.normals(key_norm, prng.STREAM_PARAM_NORMAL, 0, 0, nx * nx, 1).reshape(nx, nx),
+                normals_A=canon.normals(key_A, prng.STREAM_PARAM_NORMAL, 0, 0, nx * M, 1).reshape(nx, M))

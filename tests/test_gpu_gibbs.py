@@ -109,7 +109,7 @@ def test_pgas_chain_against_restated_chain(name, N, K):
     parameters; the restatement's own draws are compared with the device's at 1e-9).  state_trace must be equal bit for bit."""
     import torch
 
-    from common import canon_model, experiments, numpy_csmc, pgas_amd
+    from common import canon_model, experiments, host_param_draws, numpy_csmc, pgas_amd
     from oracle import pgas_numpy as o
     from pgas_amd import random as prng
 
@@ -127,7 +127,12 @@ def test_pgas_chain_against_restated_chain(name, N, K):
         step_keys.append(ks)
         para_keys.append(kp)
     assert para_keys == pg.chain_log["para_keys"] and step_keys == pg.chain_log["step_keys"]
-    draws = [pg.param_draws(kp) for kp in para_keys]
+    # the parameter draws are generated on the device; the restatement gets them recomputed on the host from the same keys
+    df = float(pb.GP_prior[3]) + (pb.T - 1)
+    draws = [host_param_draws(kp, pb.nx, pg.cSMC.engine.M, df) for kp in para_keys]
+    for kp, d in zip(para_keys, draws):
+        dd = pg.param_draws(kp)
+        assert all(np.array_equal(dd[n].cpu().numpy(), d[n]) for n in d), "device parameter draws differ from the canonical streams"
     dev_params = [(A.cpu().numpy(), S.cpu().numpy()) for A, S in pg.chain_log["params"]]
 
     cm = canon_model(pb, N)

@@ -3,7 +3,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import experiments, numpy_csmc, pgas_amd, pgas_numpy
+from common import experiments, host_param_draws, numpy_csmc, pgas_amd, pgas_numpy
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12  # fp64 tolerance of the suff-stats: summation order differs from the reference's sum over t
@@ -53,6 +53,9 @@ def test_sample_params_matches_numpy_on_same_draws():
     key = pgas_amd.random.key(99)
     draws = pg.param_draws(key)
     A, S = pg.sample_params(key, pb.X_true, draws=draws)
+    draws = {k: v.cpu().numpy() for k, v in draws.items()}
+    host = host_param_draws(key, pb.nx, pg.cSMC.engine.M, float(pb.GP_prior[3]) + (pb.T - 1))
+    assert all(np.array_equal(draws[k], host[k]) for k in host)   # device Philox draws == canonical C oracle, bit for bit
     r0, r1, r2, r3 = pgas_numpy.suff_stats(pb.X_true, _phi_numpy(pb))
     prior = tuple(np.asarray(p) for p in pb.GP_prior)
     Ao, So, _ = pgas_numpy.sample_params(prior, r0, r1, r2, r3, draws["chi2"], draws["normals_T"], draws["normals_A"])

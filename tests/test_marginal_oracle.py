@@ -116,3 +116,11 @@ def test_trajectory_basis_equals_per_step_calls(name):
         whole = bf.trajectory(X, U)
         steps = np.vstack([bf(X[t:t + 1], U[t]) for t in range(pb.T)])
         assert whole.shape == steps.shape and np.array_equal(whole, steps)
+
+
+def test_chi2_sampler_moments():
+    """canon.chi2 (the draw PGAS.sample_params' Bartlett diagonal consumes on the device): mean nu, variance 2 nu."""
+    for nu in (0.7, 3.0, 2001.0):
+        c = canon.chi2(SEED, 18, 0, 0, np.full(40000, nu))
+        assert abs(c.mean() - nu) < 5 * np.sqrt(2 * nu / 40000) and abs(c.var() - 2 * nu) < 0.1 * 2 * nu
+        assert (c > 0).all()
