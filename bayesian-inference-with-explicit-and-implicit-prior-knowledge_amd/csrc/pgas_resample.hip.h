@@ -759,8 +759,16 @@ __device__ PG_COLD_ATTR int cdf_count_wg_cold(WinSmemT<LOCAL>& sm, const ScanBuf
 // TAIL (single device, not LOCAL): the group scans of step t run inside this launch -- the workgroup that completes a group of
 // 64 segments (arrival counter) scans it -- instead of a k_groups launch between two k_step launches.  Hand-off per
 // cdna_hip_programming.md Guideline 16 (write-through payload, drained, then the counter; the last arriver acquires).
+#ifndef PG_STEP_OCC
+#define PG_STEP_OCC 5   // workgroups per CU k_step is compiled for (LDS: 5 x 31 KB; VGPR budget 512 / 5 -> 96)
+#endif
+#ifdef PG_STEP_VGPR     // experiment: waves per SIMD the register allocator targets
+#define PG_STEP_ATTR __attribute__((amdgpu_waves_per_eu(PG_STEP_VGPR, PG_STEP_VGPR)))
+#else
+#define PG_STEP_ATTR
+#endif
 template <bool LOCAL, bool TAIL = false>
-__global__ __launch_bounds__(PG_BLK, 5) void k_step(DevModel md, StepArgs ar, ScanBufs sb_prev, ScanBufs sb_next, Peers pr) {
+__global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) PG_STEP_ATTR void k_step(DevModel md, StepArgs ar, ScanBufs sb_prev, ScanBufs sb_next, Peers pr) {
     __shared__ WinSmemT<LOCAL> sm;
     const int tid = threadIdx.x;
     const int N = md.N;
