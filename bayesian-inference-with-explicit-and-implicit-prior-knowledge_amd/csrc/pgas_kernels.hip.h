@@ -398,13 +398,8 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
                 double g[JIN * NX];
 #pragma unroll
                 for (int i = 0; i < JIN * NX; ++i) g[i] = G[i];
-#ifdef PG_X_SHORTLOOP
-                constexpr int J0X = 1;
-#else
-                constexpr int J0X = J0T;
-#endif
 #pragma unroll 1
-                for (int a = 0; a < J0X; ++a) {
+                for (int a = 0; a < J0T; ++a) {
                     const double* __restrict__ Gn = G + (size_t)(a + 1 < J0T ? a + 1 : a) * JIN * NX;
                     double gn[JIN * NX];
 #pragma unroll
@@ -855,18 +850,9 @@ __device__ __forceinline__ void propagate_group(const DevModel& md, const TransP
 #pragma unroll
         for (int p = 0; p < P; ++p) {
             const int64_t pi = (int64_t)seg * PGAS_SEG + (r0 + p) * PG_BLK + tid;
-#ifdef PG_X_NOPHILOX
-            w[p].v[0] = (uint32_t)pi * 2654435761u; w[p].v[1] = (uint32_t)t + 12345u; w[p].v[2] = (uint32_t)pi ^ 0x9e3779b9u; w[p].v[3] = (uint32_t)seed;
-#else
             w[p] = pgas_rng_block(seed, PGAS_STREAM_PROP, 0u, (uint32_t)t, (uint64_t)(md.p0 + pi));
-#endif
         }
-#ifdef PG_X_NOBM
-#pragma unroll
-        for (int p = 0; p < P; ++p) { z0[p] = (double)w[p].v[0] * 0x1p-32; z1[p] = (double)w[p].v[2] * 0x1p-32; }
-#else
         pgas_normal_pair_n(w, z0, z1, P);
-#endif
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -980,13 +966,9 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
                             for (int k = 0; k < NX; ++k) xt[pi * NX + k] = xn[p][k];
                         }
                     }
-#ifdef PG_X_NOSTORE   // timing experiment only: keep the values live, skip the hand-off stores
-                    asm volatile("" ::"v"(la[p]), "v"(h[p]), "v"(ln[p]));
-#else
                     la_buf[(size_t)t * np + pi] = la[p];
                     h_buf[(size_t)t * np + pi] = h[p];
                     ln_buf[(size_t)t * np + pi] = ln[p];
-#endif
                     if constexpr (!ONE) {
 #pragma unroll
                         for (int k = 0; k < NX; ++k) xv[r0 + p][k] = xn[p][k];

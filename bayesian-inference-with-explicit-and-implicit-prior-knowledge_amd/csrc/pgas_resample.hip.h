@@ -762,13 +762,8 @@ __device__ PG_COLD_ATTR int cdf_count_wg_cold(WinSmemT<LOCAL>& sm, const ScanBuf
 #ifndef PG_STEP_OCC
 #define PG_STEP_OCC 5   // workgroups per CU k_step is compiled for (LDS: 5 x 31 KB; VGPR budget 512 / 5 -> 96)
 #endif
-#ifdef PG_STEP_VGPR     // experiment: waves per SIMD the register allocator targets
-#define PG_STEP_ATTR __attribute__((amdgpu_waves_per_eu(PG_STEP_VGPR, PG_STEP_VGPR)))
-#else
-#define PG_STEP_ATTR
-#endif
 template <bool LOCAL, bool TAIL = false>
-__global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) PG_STEP_ATTR void k_step(DevModel md, StepArgs ar, ScanBufs sb_prev, ScanBufs sb_next, Peers pr) {
+__global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepArgs ar, ScanBufs sb_prev, ScanBufs sb_next, Peers pr) {
     __shared__ WinSmemT<LOCAL> sm;
     const int tid = threadIdx.x;
     const int N = md.N;
@@ -859,6 +854,7 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) PG_STEP_ATTR void k_step(DevMo
         }
         PG_STAMP(6);
         segment_scan<2, false, TAIL>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segk_w, sb_next.segs_w);
+        PG_STAMP(8);
         if constexpr (TAIL) {
             if (tid < 64) {   // wave 0: lane 0 stored the partials above
                 const int g = seg / PG_GRP;
