@@ -760,7 +760,7 @@ __device__ PG_COLD_ATTR int cdf_count_wg_cold(WinSmemT<LOCAL>& sm, const ScanBuf
 // 64 segments (arrival counter) scans it -- instead of a k_groups launch between two k_step launches.  Hand-off per
 // cdna_hip_programming.md Guideline 16 (write-through payload, drained, then the counter; the last arriver acquires).
 #ifndef PG_STEP_OCC
-#define PG_STEP_OCC 5   // workgroups per CU k_step is compiled for (LDS: 5 x 31 KB; VGPR budget 512 / 5 -> 96)
+#define PG_STEP_OCC 4   // waves per SIMD k_step is compiled for: 4 -> 108 VGPRs and no scratch; 5 (the LDS limit, 5 x 31 KB) -> 96 VGPRs + 36 B/lane of scratch = 15 MB more HBM traffic per launch at the same speed
 #endif
 template <bool LOCAL, bool TAIL = false>
 __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepArgs ar, ScanBufs sb_prev, ScanBufs sb_next, Peers pr) {

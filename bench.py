@@ -27,6 +27,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 ALG_BYTES_PER_PARTICLE_STEP = 52  # 16 nx + 20, nx = 2
+FP64_VECTOR_PEAK_TFLOPS = 78.6     # MI355X_MICROARCH.md: fp64 vector (= fp64 matrix) peak
 
 
 def cpu_baseline(pb, A, S, N, seed, steps):
@@ -400,6 +401,14 @@ def main():
                         if "valu" in tj:
                             out["valu"] = tj["valu"]
                         break
+            # SURVEY 8(d), secondary figure: algorithmic flops per particle-step = 2 M nx (Phi A^T) + M (D - 1) (products) against the
+            # fp64 vector peak -- the bound that matters for the M = 729 configurations
+            flops_ps = 2 * eng.M * nxv + eng.M * (Dv - 1)
+            out["valu_roofline"] = {
+                "flops_per_particle_step": flops_ps, "achieved": flops_ps * units / dt / world / 1e12, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": flops_ps * units / dt / world / 1e12 / FP64_VECTOR_PEAK_TFLOPS,
+                "note": "whole sweep; flops = 2 M nx + M (D - 1) per particle-step (SURVEY.md section 8d), sines, random numbers and the weight recursion not counted",
+            }
             out["roofline"] = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_src, "kernel": dom["kernel"], "avg_launch_us": dom["avg_launch_us"],
