@@ -19,6 +19,9 @@
 #include "pgas_marginal.hip.h"
 #include "../../include/pgas_marginal.h"
 
+#ifndef PG_W3
+#define PG_W3 2    // waves per SIMD the 3-D k_propagate instantiations are compiled for
+#endif
 #ifndef PG_W28
 #define PG_W28 2
 #endif
@@ -131,7 +134,7 @@ bool pick_variant(int nx, int D, int jin_needed, bool fast, int J0, Variant* v, 
         else *v = jp == 8 ? make_variant<1, 3, 8, 2, 2>() : jp == 12 ? make_variant<1, 3, 12, 2, 2>() : make_variant<1, 3, 16, 2, 2>();
     } else {
         if (D == 2) *v = jp == 8 ? make_variant<2, 2, 8, 2, PG_W28>() : jp == 12 ? make_variant<2, 2, 12, 2, 2>() : make_variant<2, 2, 16, 2, 2>();
-        else *v = jp == 8 ? make_variant<2, 3, 8, PG_P3, 2, 0, PG_PPT3>() : jp == 12 ? make_variant<2, 3, 12, PG_P3, 2, 0, PG_PPT3>() : make_variant<2, 3, 16, PG_P3, 2, 0, PG_PPT3>();
+        else *v = jp == 8 ? make_variant<2, 3, 8, PG_P3, PG_W3, 0, PG_PPT3>() : jp == 12 ? make_variant<2, 3, 12, PG_P3, PG_W3, 0, PG_PPT3>() : make_variant<2, 3, 16, PG_P3, PG_W3, 0, PG_PPT3>();
     }
     return true;
 }
@@ -205,6 +208,7 @@ struct pgas_ctx {
     double* d_syrk_ws = nullptr;   // split-K partial slabs of Z^T Z (pgas_suffstats)
     size_t syrk_ws_bytes = 0;
     int syrk_splits = 0;           // 0 = automatic
+    bool peer_access_tried = false;
     // optional per-launch timing of the dominant kernel (pgas_set_profiling)
     int profiling = 0;
     int prof_stride = 16;       // every prof_stride-th launch carries start/stop events (hipExtLaunchKernelGGL: the dispatch's own timestamps)
@@ -1199,6 +1203,16 @@ int pgas_ipc_open(pgas_ctx* c, const void* handle64, void** ptr) {
     if (!c) return PGAS_E_ARG;
     if (!handle64 || !ptr) FAIL(c, PGAS_E_ARG, "pgas_ipc_open: NULL argument");
     DeviceGuard guard(c->device);
+    if (!c->peer_access_tried) {   // best effort, once: let this device's kernels reach every other device of the node (xGMI)
+        c->peer_access_tried = true;
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) == hipSuccess)
+            for (int d = 0; d < ndev; ++d) {
+                int can = 0;
+                if (d != c->device && hipDeviceCanAccessPeer(&can, c->device, d) == hipSuccess && can) (void)hipDeviceEnablePeerAccess(d, 0);
+            }
+        (void)hipGetLastError();   // "already enabled" is not an error here
+    }
     hipIpcMemHandle_t h;
     memcpy(&h, handle64, sizeof h);
     HIPCHK(c, hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess));

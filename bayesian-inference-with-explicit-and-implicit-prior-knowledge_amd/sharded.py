@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import random as prng
-from ._lib import Engine
+from ._lib import Engine, PgasError
 
 PH_INIT, PH_PROPAGATE, PH_STEP, PH_GROUPS, PH_FINAL_SCAN, PH_FINAL, PH_BACKTRACE = range(7)
 
@@ -81,16 +81,34 @@ class DistGroup:
         handles = [shard.eng.ipc_export(k) for k in range(7)]
         everyone = [None] * world
         dist.all_gather_object(everyone, handles, group=group)
-        for peer, hs in enumerate(everyone):
-            if peer == rank:
-                shard.eng.shard_set_peer(peer, shard.ptrs[:7])
-            else:
-                shard.eng.shard_set_peer(peer, [shard.eng.ipc_open(h) for h in hs])
         self.backend = dist.get_backend(group)
+
+        def agreed(step, fn):
+            """Run the local part of a setup step and agree on its outcome: a failure on one rank raises on every rank instead
+            of leaving the others waiting in the next collective."""
+            err = None
+            try:
+                fn()
+            except Exception as e:   # noqa: BLE001  (reported below, on every rank)
+                err = f"rank {rank}: {type(e).__name__}: {e}"
+            errs = [None] * world
+            dist.all_gather_object(errs, err, group=group)
+            bad = [e for e in errs if e]
+            if bad:
+                raise PgasError(f"sharded sweep setup failed at '{step}': " + "; ".join(bad))
+
+        def open_peers():
+            for peer, hs in enumerate(everyone):
+                if peer == rank:
+                    shard.eng.shard_set_peer(peer, shard.ptrs[:7])
+                else:
+                    shard.eng.shard_set_peer(peer, [shard.eng.ipc_open(h) for h in hs])
+
+        agreed("open the peers' IPC handles", open_peers)
         if self.backend == "nccl":
             ident = [shard.eng.shard_unique_id() if rank == 0 else None]
             dist.broadcast_object_list(ident, src=0, group=group)
-            shard.eng.shard_comm_init(ident[0])
+            agreed("RCCL communicator", lambda: shard.eng.shard_comm_init(ident[0]))
         else:
             shard.eng.shard_set_collective(self._host_all_gather)
 
