@@ -288,6 +288,29 @@ def test_sharded_sweep_bit_exact_and_independent_of_world(name, N, world):
         _eq(LW, lwo[r * Nl:(r + 1) * Nl], f"log_weights shard {r}")
 
 
+def test_eight_shards_five_million_particles():
+    """The geometry of BASELINE config 4 beyond what one window holds: 8 shards x 640 segments = 5120 segments = 80 groups (the top
+    level scans two blocks of groups, every workgroup's window is a small part of the device, most peers are remote).  T = 3,
+    traces and trajectory against the oracle bit for bit."""
+    from pgas_amd import sharded
+
+    world, Nl = 8, 640 * 1024
+    N = world * Nl
+    pb = experiments.smo_pgas(T=3)
+    A, S = experiments.initial_params(pb)
+    cm = canon_model(pb, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    trajo, Xo, ANCo, lwo = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
+    grp = sharded.make_local_group(world, N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+    trajs = sharded.sharded_sweep(grp, SEED, pb.X_true, A, S)
+    for r, (s, tr) in enumerate(zip(grp.shards, trajs)):
+        _eq(tr, trajo.reshape(tr.shape), f"trajectory on rank {r}")
+        X, ANC, LW, _ = s.eng.traces()
+        _eq(X, Xo[:, r * Nl:(r + 1) * Nl], f"state_trace shard {r}")
+        _eq(ANC[: pb.T - 1], ANCo[:, r * Nl:(r + 1) * Nl], f"ancestor_trace shard {r}")
+        _eq(LW, lwo[r * Nl:(r + 1) * Nl], f"log_weights shard {r}")
+
+
 def test_filtering_free_functions():
     """src/Filtering.py mirror: systematic_SISR KATs and reconstruct_trajectory on a hand-built ancestry."""
     from oracle import pgas_numpy as o
