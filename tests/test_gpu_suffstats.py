@@ -47,6 +47,20 @@ def test_suffstats_full_size(maker, splits):
     assert torch.equal(T1, T1.T) and T3 == r3
 
 
+@pytest.mark.parametrize("M,T", [(62, 37), (63, 37), (64, 37), (65, 21), (127, 18), (128, 18), (64, 2), (27, 3)])
+def test_suffstats_block_boundaries(M, T):
+    """[Phi | X+] column counts around the 64-wide SYRK block (X+ inside the last block, straddling two blocks, alone in a new block)
+    and row counts below one 16-row panel."""
+    pb = experiments.emps_pgas(T=T, M=M)
+    pg = pgas_amd.PGAS(256, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior, pb.basis_fcn)
+    T0, T1, T2, T3 = pg.cSMC.engine.suffstats(pb.X_true)
+    r0, r1, r2, r3 = pgas_numpy.suff_stats(pb.X_true, _phi_numpy(pb))
+    for g, r, nm in ((T0, r0, "T0"), (T1, r1, "T1"), (T2, r2, "T2")):
+        g = g.cpu().numpy()
+        assert g.shape == r.shape and np.abs(g - r).max() <= RTOL * max(np.abs(r).max(), 1e-300) * pb.T, f"{nm} (M={M}, T={T}): max |d| = {np.abs(g - r).max():.3e}"
+    assert torch.equal(T1, T1.T) and torch.equal(T2, T2.T) and T3 == r3
+
+
 def test_sample_params_matches_numpy_on_same_draws():
     pb = experiments.smo_pgas(T=200)
     pg = pgas_amd.PGAS(256, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior, pb.basis_fcn)
