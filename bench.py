@@ -401,7 +401,7 @@ def main():
             oth["achieved_GBs"] = per_launch * oth["steps_per_launch"] / (oth["avg_launch_us"] * 1e-6) / 1e9
             sweep_GBs = ALG_BYTES_PER_PARTICLE_STEP * units / dt / world / 1e9   # per GPU
             traffic, traffic_src = None, None
-            for tf in ("traffic_r02.json", "traffic_r01.json"):
+            for tf in (("traffic_r02.json", "traffic_r01.json") if args.workload == "smo" else ()):   # the stored counters are of the smo workload
                 tp = os.path.join(ROOT, "profiles", tf)
                 if os.path.exists(tp):
                     tj = json.load(open(tp))

@@ -25,7 +25,7 @@ tools/pmc_sq.sh $R
 python3 tools/make_traffic.py $O $O/traffic_$R.json > /dev/null && echo traffic json written
 
 # pgas_suffstats at M = 729, T = 2000 (EMPS): per-kernel durations and the f64 MFMA counters of k_syrk_lds
-ONLY=EMPS timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sy -- python3 tools/syrk_time.py 0 > $O/syrk_time.txt 2>&1
+ONLY=EMPS timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sy -- python3 tools/syrk_time.py 0 2>/dev/null | grep 'pgas_suffstats call' > $O/syrk_time.txt
 grep -h "Name\|k_syrk\|k_traj" $O/sy/*/*kernel_stats.csv > $O/syrk_kernel_stats.csv; rm -rf $O/sy; cat $O/syrk_time.txt $O/syrk_kernel_stats.csv
 ONLY=EMPS timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/sp -- python3 tools/syrk_time.py 0 > /dev/null 2> $O/syrk_pmc.err
 python3 tools/pmc_kernels.py $O/sp raw | grep "syrk\|traj" > $O/syrk_pmc.txt; rm -rf $O/sp; cat $O/syrk_pmc.txt
