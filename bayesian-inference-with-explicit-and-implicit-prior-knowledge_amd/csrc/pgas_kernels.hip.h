@@ -44,6 +44,34 @@ __device__ unsigned long long g_stamps[2048 * 16];
 #define PG_STAMP(id) do { } while (0)
 #endif
 
+
+// Streaming hints: data written once and read much later (x_t, the la / h / ln hand-off rows, the ancestor trace) is stored
+// non-temporally so that it does not occupy this XCD's L2: 84.9 -> 81.2 ms per SMO sweep.  Measured and NOT adopted: the same for the
+// fixed-point CDF (82.2 ms; the next launch's neighbours re-read it) and non-temporal LOADS of the hand-off rows / x_{t-1} (86 ms).
+#ifndef PG_NO_STREAM_STORES
+#define PG_NT_X
+#define PG_NT_H
+#define PG_NT_STORES
+#endif
+typedef double pg_nt_d2 __attribute__((ext_vector_type(2)));
+typedef unsigned long long pg_nt_u2 __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ void st_stream(T* p, T v) {
+#ifdef PG_NT_STORES
+    __builtin_nontemporal_store(v, p);
+#else
+    *p = v;
+#endif
+}
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) {
+#ifdef PG_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 struct DevModel {
     int32_t N, T, nx, ny, nu, D, M;
     int32_t J[PGAS_MAX_D], j0[PGAS_MAX_D], jstep[PGAS_MAX_D], sel[PGAS_MAX_D];
@@ -679,8 +707,14 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
         if (w == 0 || STORE_B) {
             const uint64_t base = off + incl[w] - loc[w][PG_PPT - 1];
             ulonglong2* dst = reinterpret_cast<ulonglong2*>((w == 0 ? cA : cB) + (size_t)seg * PGAS_SEG + PG_PPT * tid);
+#ifdef PG_NT_C1
+            pg_nt_u2* dn = reinterpret_cast<pg_nt_u2*>(dst);
+            __builtin_nontemporal_store(pg_nt_u2{base + loc[w][0], base + loc[w][1]}, dn);
+            __builtin_nontemporal_store(pg_nt_u2{base + loc[w][2], base + loc[w][3]}, dn + 1);
+#else
             dst[0] = make_ulonglong2(base + loc[w][0], base + loc[w][1]);
             dst[1] = make_ulonglong2(base + loc[w][2], base + loc[w][3]);
+#endif
         }
         if (tid == 0) {
             if constexpr (HANDOFF) {
@@ -924,7 +958,11 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
             size_t pi = particle(r);
             if (pi >= (size_t)md.N) pi = md.N - 1;
             if constexpr (NX == 2) {
+#ifdef PG_NT_LOADS
+                const pg_nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const pg_nt_d2*>(x_trace + (size_t)(t0 - 1) * row) + pi);
+#else
                 const double2 v = reinterpret_cast<const double2*>(x_trace + (size_t)(t0 - 1) * row)[pi];
+#endif
                 xr[0] = v.x;
                 xr[1] = v.y;
             } else {
@@ -973,15 +1011,27 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
                     const size_t pi = particle(r0 + p);   // la / h / ln are padded to nseg*SEG
                     if (pi < (size_t)md.N) {
                         if constexpr (NX == 2) {
+#ifdef PG_NT_X
+                            typedef double pg_d2 __attribute__((ext_vector_type(2)));
+                            pg_d2 v2 = {xn[p][0], xn[p][1]};
+                            __builtin_nontemporal_store(v2, reinterpret_cast<pg_d2*>(xt) + pi);
+#else
                             reinterpret_cast<double2*>(xt)[pi] = make_double2(xn[p][0], xn[p][1]);
+#endif
                         } else {
 #pragma unroll
                             for (int k = 0; k < NX; ++k) xt[pi * NX + k] = xn[p][k];
                         }
                     }
+#ifdef PG_NT_H
+                    __builtin_nontemporal_store(la[p], &la_buf[(size_t)t * np + pi]);
+                    __builtin_nontemporal_store(h[p], &h_buf[(size_t)t * np + pi]);
+                    __builtin_nontemporal_store(ln[p], &ln_buf[(size_t)t * np + pi]);
+#else
                     la_buf[(size_t)t * np + pi] = la[p];
                     h_buf[(size_t)t * np + pi] = h[p];
                     ln_buf[(size_t)t * np + pi] = ln[p];
+#endif
                     if constexpr (!ONE) {
 #pragma unroll
                         for (int k = 0; k < NX; ++k) xv[r0 + p][k] = xn[p][k];

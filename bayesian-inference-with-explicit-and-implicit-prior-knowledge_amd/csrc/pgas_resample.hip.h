@@ -784,7 +784,7 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
     // own-particle inputs first: their latency overlaps the scans below
     double lnv[PG_PPT];
 #pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) lnv[r] = (ar.mode & PG_RS_SEARCH) ? ar.ln_prev[(size_t)base_i + r * PG_BLK + tid] : 0.0;
+    for (int r = 0; r < PG_PPT; ++r) lnv[r] = (ar.mode & PG_RS_SEARCH) ? ld_stream(&ar.ln_prev[(size_t)base_i + r * PG_BLK + tid]) : 0.0;
     double lwp[PG_PPT] = {0.0, 0.0, 0.0, 0.0};
     if (ar.mode & PG_RS_SEARCH) {
         int a[PG_PPT];
@@ -819,7 +819,7 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
 #pragma unroll
         for (int j = 0; j < PG_PPT; ++j) {
             sm.u.a[slot_of(tid, j)] = a[j];
-            if (base_i + slot_of(tid, j) < N) ar.anc_out[base_i + slot_of(tid, j)] = a[j];
+            if (base_i + slot_of(tid, j) < N) st_stream(&ar.anc_out[base_i + slot_of(tid, j)], (int32_t)a[j]);
         }
         __syncthreads();
 #pragma unroll
@@ -848,9 +848,9 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
         for (int r = 0; r < PG_PPT; ++r) {
             const size_t pi = (size_t)base_i + r * PG_BLK + tid;
             const bool valid_p = pi < (size_t)N;
-            const double l1 = ar.la_t[pi] + lwp[r];
+            const double l1 = ld_stream(&ar.la_t[pi]) + lwp[r];
             lw[0][r] = valid_p ? l1 : -__builtin_inf();
-            lw[1][r] = valid_p ? l1 + ar.h_t[pi] : -__builtin_inf();
+            lw[1][r] = valid_p ? l1 + ld_stream(&ar.h_t[pi]) : -__builtin_inf();
         }
         PG_STAMP(6);
         segment_scan<2, false, TAIL>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segk_w, sb_next.segs_w);
