@@ -209,6 +209,8 @@ struct pgas_ctx {
     size_t syrk_ws_bytes = 0;
     int syrk_splits = 0;           // 0 = automatic
     bool peer_access_tried = false;
+    int max_lead = 0;              // PGAS_OPT_MAX_LEAD
+    std::vector<hipEvent_t> ev_bdone;
     // optional per-launch timing of the dominant kernel (pgas_set_profiling)
     int profiling = 0;
     int prof_stride = 16;       // every prof_stride-th launch carries start/stop events (hipExtLaunchKernelGGL: the dispatch's own timestamps)
@@ -410,6 +412,7 @@ void pgas_destroy(pgas_ctx* c) {
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (hipEvent_t e : c->evp) hipEventDestroy(e);
     for (hipEvent_t e : c->ev_chunk) hipEventDestroy(e);
+    for (hipEvent_t e : c->ev_bdone) hipEventDestroy(e);
     if (c->ev_start) hipEventDestroy(c->ev_start);
     if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->sB) hipStreamDestroy(c->sB);
@@ -674,8 +677,20 @@ static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int 
     // group (not per chunk) gates pipeline B: a marker packet between two consecutive k_propagate launches costs pipeline A a
     // command-processor round trip per step, and B trails A by more than a group anyway.
     const int stride = c->ev_stride > 0 ? c->ev_stride : 1;
+    // PGAS_OPT_MAX_LEAD: pipeline A may run at most `max_lead` groups ahead of pipeline B, so that the hand-off rows B reads are
+    // still in the memory-side cache when it gets to them (0 = unbounded)
+    const int lead = sB != st ? c->max_lead : 0;
+    const int ngroups = (nchunk + stride - 1) / stride;
+    if (lead > 0)
+        while ((int)c->ev_bdone.size() < ngroups) {
+            hipEvent_t e;
+            HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            c->ev_bdone.push_back(e);
+        }
     for (int c0 = 0; c0 < nchunk; c0 += stride) {
         const int c1 = c0 + stride < nchunk ? c0 + stride : nchunk;
+        const int gi = c0 / stride;
+        if (lead > 0 && gi >= lead) HIPCHK(c, hipStreamWaitEvent(st, c->ev_bdone[gi - lead], 0));
         for (int ci = c0; ci < c1; ++ci) {
             const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
             int rc = launch_propagate(c, seed, t0, t1, ref_dev, st, c->profiling && (ci % c->prof_stride) == 0);
@@ -703,6 +718,7 @@ static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int 
                 if (rc) return rc;
             }
         }
+        if (lead > 0) HIPCHK(c, hipEventRecord(c->ev_bdone[gi], sB));
     }
     if (sB != st) {
         HIPCHK(c, hipEventRecord(c->ev_done, sB));
@@ -829,6 +845,11 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
     }
     if (option == PGAS_OPT_TAIL_GROUPS) {
         c->tail_groups = value ? 1 : 0;
+        return PGAS_OK;
+    }
+    if (option == PGAS_OPT_MAX_LEAD) {
+        if (value < 0) FAIL(c, PGAS_E_ARG, "pgas_set_option: max lead must be >= 0");
+        c->max_lead = (int)value;
         return PGAS_OK;
     }
     if (option == PGAS_OPT_SYRK_SPLITS) {

@@ -222,6 +222,7 @@ def main():
     ap.add_argument("--tail-groups", action="store_true", help="group scans in k_step's tail (in-launch hand-off) instead of k_groups launches between the steps")
     ap.add_argument("--local-groups", action="store_true", help="k_step<LOCAL>: every workgroup scans all groups itself instead of a k_groups launch between the steps")
     ap.add_argument("--event-stride", type=int, default=-1, help="k_propagate launches per gating event (engine default if < 0)")
+    ap.add_argument("--max-lead", type=int, default=-1, help="PGAS_OPT_MAX_LEAD: event groups k_propagate may run ahead of the weight recursion (engine default if < 0)")
     ap.add_argument("--no-overlap", action="store_true", help="run the weight recursion on the caller's stream (no concurrency)")
     ap.add_argument("--prop-lds", type=int, default=-1, help="LDS bytes reserved per k_propagate workgroup while overlapping (engine default if < 0)")
     ap.add_argument("--workload", choices=["smo", "vehicle", "emps", "smo-alg1"], default="smo",
@@ -313,6 +314,8 @@ def main():
         eng.set_option(9, 1)               # PGAS_OPT_TAIL_GROUPS
     if args.event_stride > 0:
         eng.set_option(8, args.event_stride)   # PGAS_OPT_EVENT_STRIDE
+    if args.max_lead >= 0:
+        eng.set_option(11, args.max_lead)      # PGAS_OPT_MAX_LEAD
     if args.no_overlap:
         eng.set_option(3, 0)               # PGAS_OPT_OVERLAP
     if args.prop_lds >= 0:

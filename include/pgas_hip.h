@@ -145,6 +145,7 @@ int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
  * three launches.  Default 0 = reproduce the reference. */
 #define PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE 5
 #define PGAS_OPT_LOCAL_GROUPS 7 /* 1: on a single device with <= 1024 segments every k_step workgroup scans all groups itself (k_step<LOCAL>, no k_groups launch between the steps); default 0, the k_groups path is faster */
+#define PGAS_OPT_MAX_LEAD 11 /* sweep: k_propagate may run at most this many event groups (PGAS_OPT_EVENT_STRIDE steps each) ahead of the weight recursion; 0 = unbounded */
 #define PGAS_OPT_SYRK_SPLITS 10 /* pgas_suffstats: number of row splits of the Z^T Z product (partial slabs summed in split order); 0 = automatic (about two workgroups per CU) */
 #define PGAS_OPT_TAIL_GROUPS 9 /* 1: single device only: the group scans ride in k_step's tail (in-launch hand-off to the workgroup that completes a group) instead of k_groups launches; measured slower, default 0 */
 #define PGAS_OPT_EVENT_STRIDE 8 /* k_propagate launches per event that gates the weight recursion's stream (default 8) */
