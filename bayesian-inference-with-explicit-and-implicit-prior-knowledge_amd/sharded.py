@@ -65,6 +65,22 @@ class LocalGroup:
         torch.cuda.synchronize()
 
 
+def agree_on(dist, group, step, fn):
+    """Run the local part `fn` of a setup step and agree on its outcome across the ranks of `group`: a failure on one rank raises
+    PgasError on every rank instead of leaving the others waiting in the next collective."""
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    err = None
+    try:
+        fn()
+    except Exception as e:   # noqa: BLE001  (reported below, on every rank)
+        err = f"rank {rank}: {type(e).__name__}: {e}"
+    errs = [None] * world
+    dist.all_gather_object(errs, err, group=group)
+    bad = [e for e in errs if e]
+    if bad:
+        raise PgasError(f"sharded sweep setup failed at '{step}': " + "; ".join(bad))
+
+
 class DistGroup:
     """One shard per process.  The time loop runs inside the library (pgas_shard_sweep) on every backend:
       * "nccl": the per-step all-gather is an RCCL call on the sweep's stream (own communicator; torch.distributed only carries
@@ -84,18 +100,7 @@ class DistGroup:
         self.backend = dist.get_backend(group)
 
         def agreed(step, fn):
-            """Run the local part of a setup step and agree on its outcome: a failure on one rank raises on every rank instead
-            of leaving the others waiting in the next collective."""
-            err = None
-            try:
-                fn()
-            except Exception as e:   # noqa: BLE001  (reported below, on every rank)
-                err = f"rank {rank}: {type(e).__name__}: {e}"
-            errs = [None] * world
-            dist.all_gather_object(errs, err, group=group)
-            bad = [e for e in errs if e]
-            if bad:
-                raise PgasError(f"sharded sweep setup failed at '{step}': " + "; ".join(bad))
+            agree_on(dist, group, step, fn)
 
         def open_peers():
             for peer, hs in enumerate(everyone):

@@ -96,3 +96,49 @@ def test_shard_layout():
         shard_layout(5000, 2)
     with pytest.raises(ValueError):
         shard_layout(3072, 2)
+
+
+def _agree_worker(rank, world, port, q):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pgas_amd.sharded import PgasError, agree_on
+
+        agree_on(dist, None, "a step every rank completes", lambda: None)   # no error anywhere: returns on every rank
+
+        def local_part():
+            if rank == 1:
+                raise RuntimeError("cannot map the peer's buffer")
+
+        try:
+            agree_on(dist, None, "open the peers' IPC handles", local_part)
+            q.put((rank, "no error raised"))
+        except PgasError as e:
+            q.put((rank, str(e)))
+        dist.barrier()   # every rank is still in step with the others afterwards
+    finally:
+        dist.destroy_process_group()
+
+
+def test_setup_failure_on_one_rank_raises_on_every_rank():
+    """pgas_amd.sharded.agree_on: what keeps a multi-GPU run from hanging when one rank cannot open a peer's IPC handle or build
+    its RCCL communicator -- every rank gets the same PgasError (bench.py then falls back to independent chains)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_agree_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        got = dict(q.get(timeout=120) for _ in range(world))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert set(got) == {0, 1}
+    for r in (0, 1):
+        assert "open the peers' IPC handles" in got[r] and "rank 1: RuntimeError: cannot map the peer's buffer" in got[r], got
