@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 from . import random as prng
-from .Algorithm1 import Algorithm3, _t
+from .Algorithm1 import _t
+from .Algorithm3 import Algorithm3
 
 
 class Algorithm2:

@@ -20,7 +20,8 @@ from .BayesianInferrence import (  # noqa: F401
 )
 from .descriptors import BasisMap, GaussianLikelihood, HilbertBasis  # noqa: F401
 from .Filtering import reconstruct_trajectory, systematic_SISR  # noqa: F401
-from .Algorithm1 import Algorithm1, Algorithm3  # noqa: F401
+from .Algorithm1 import Algorithm1  # noqa: F401
+from .Algorithm3 import Algorithm3  # noqa: F401
 from .Algorithm2 import Algorithm2  # noqa: F401
 from .PGAS import PGAS, condSequentialMonteCarlo  # noqa: F401
 from .StateSpaceModel import StateSpaceModel  # noqa: F401
