@@ -38,6 +38,9 @@ class DeviceRand:
     def uniform(self, stream, t):
         return self.ops.uniform(self.seed, stream, t)
 
+    def uniform_dev(self, stream, t):
+        return self.ops.uniform_dev(self.seed, stream, t)
+
     def student_t(self, stream, t, nu):
         return self.ops.student_t(self.seed, stream, t, nu)
 
@@ -73,6 +76,17 @@ class Algorithm1:
             self.GP_prior.append((_t(e0.reshape(-1), dev).contiguous(), _t(e1, dev).contiguous(), float(e2[0, 0]), float(g[3])))
 
     # ---------------------------------------------------------------------------------------------------------------- helpers
+    _tidx = None   # graph mode: (t, t - 1) as one-element int64 device tensors; rows are then gathered on the device
+
+    def _inp(self, time, back=0):
+        """inputs[time - back]; in graph mode the row is selected on the device from the time tensor."""
+        if self._tidx is None:
+            return self.inputs[time - back]
+        return self.inputs.index_select(0, self._tidx[back]).squeeze(0)
+
+    def _obs(self, time):
+        return self.observations[time] if self._tidx is None else self.observations.index_select(0, self._tidx[0]).squeeze(0)
+
     def _rand(self, key):
         return key if hasattr(key, "student_t") else DeviceRand(self.ops, prng.as_key(key))
 
@@ -120,10 +134,10 @@ class Algorithm1:
         """Returns (aux_state, aux_int_var, factors).  factors[i] keeps, per particle, the Cholesky factor of eta1 = prior + scale T1,
         w = L^-1 eta0, q = w . w and log det eta1: the resampled children reuse them in _draw_int_vars (their matrix is their
         ancestor's, :358-361) and Algorithm3 reads q / logdet for its base measures -- one factorisation per particle and step."""
-        aux_state = self.SSM.transition_mdl(state, self.inputs[time - 1], *int_var)        # :206-208
+        aux_state = self.SSM.transition_mdl(state, self._inp(time, 1), *int_var)        # :206-208
         aux_int_var, factors = [], []
         for i in range(self.N_int):
-            basis = self.basis_fcn[i](aux_state, self.inputs[time]).contiguous()           # :220-225
+            basis = self.basis_fcn[i](aux_state, self._inp(time)).contiguous()              # :220-225
             P0, P1, _, _ = self.GP_prior[i]
             # mean_i phi = eta0^T eta1^-1 phi (BI:48-50, :228-231); `scale` carries the forgetting factor of :317-320
             sol = self.ops.mniw_solve(P0, P1, suff_stats[i][0], suff_stats[i][1], scale=scale, phi=basis, want=("m", "q", "logdet"), keep_factor=True)
@@ -138,7 +152,7 @@ class Algorithm1:
         int_var, basis_all = [], []
         ai = a.long()
         for i in range(self.N_int):
-            basis = self.basis_fcn[i](state, self.inputs[time]).contiguous()               # :243-248
+            basis = self.basis_fcn[i](state, self._inp(time)).contiguous()                  # :243-248
             _, _, P2, P3 = self.GP_prior[i]
             _, _, T2, T3 = suff_stats[i]
             sol = self.ops.mniw_trisolve(factors[i], a, basis)                             # m = mean phi (BI:81), c = phi^T col_cov phi (BI:84)
@@ -155,7 +169,7 @@ class Algorithm1:
     def _draw_states(self, rand, time, state, int_var, a):
         ai = a.long()
         z = rand.normal(STREAM_STATE, time, state.shape[1])
-        return self.SSM.draw_state(z, state[ai], self.inputs[time - 1], *[v[ai] for v in int_var])
+        return self.SSM.draw_state(z, state[ai], self._inp(time, 1), *[v[ai] for v in int_var])
 
     # ------------------------------------------------------------------------------------------------------ :297-397
     def step(self, key, time, log_weights, state, int_var, suff_stats):
@@ -165,29 +179,92 @@ class Algorithm1:
         suff_stats = self._dev_shapes(suff_stats)
         # :317-320 statistics time update: the factor is applied inside the kernels (scale * T), never materialised
         aux_state, aux_int_var, factors = self._generate_auxiliary_states(state, time, int_var, suff_stats, scale=lam)   # :323-325
-        ll_aux = self.SSM.log_likelihood(self.observations[time], aux_state, self.inputs[time], *aux_int_var)    # :328-341
-        a = self.ops.systematic_resample(rand.uniform(STREAM_RESAMPLE, time), (ll_aux + log_weights).contiguous())   # :342-347
+        ll_aux = self.SSM.log_likelihood(self._obs(time), aux_state, self._inp(time), *aux_int_var)    # :328-341
+        u = rand.uniform(STREAM_RESAMPLE, time) if self._tidx is None else rand.uniform_dev(STREAM_RESAMPLE, time)
+        a = self.ops.systematic_resample(u, (ll_aux + log_weights).contiguous())       # :342-347
         new_state = self._draw_states(rand, time, state, int_var, a)                       # :350-353
         new_int_var, new_basis = self._draw_int_vars(rand, time, new_state, suff_stats, a, factors, scale=lam)   # :358-367
         new_stats = tuple(self.ops.stats_gather_update(lam, a, suff_stats[i], new_basis[i], new_int_var[i].reshape(-1))
                           for i in range(self.N_int))                                      # :370-377
-        new_lw = self.SSM.log_likelihood(self.observations[time], new_state, self.inputs[time], *new_int_var) - ll_aux[a.long()]   # :380-390
+        new_lw = self.SSM.log_likelihood(self._obs(time), new_state, self._inp(time), *new_int_var) - ll_aux[a.long()]   # :380-390
         return new_lw, new_state, new_int_var, new_stats, a
 
     # ------------------------------------------------------------------------------------------------------ :399-492
-    def __call__(self, key):
+    def _loop_body(self, rand, time, traces, suff_stats):
+        """One iteration of the reference loop (:418-457) against the trace arrays; returns the new per-particle statistics."""
+        state_trace, int_var_trace, sst, lw_trace, anc_trace = traces
+        if self._tidx is None:
+            prev = lambda a: a[time - 1]                                                   # noqa: E731
+            put = lambda a, v, back=0: a.__setitem__(time - back, v.reshape(a.shape[1:]))   # noqa: E731
+        else:   # graph mode: rows addressed through the device-resident time index
+            prev = lambda a: a.index_select(0, self._tidx[1]).squeeze(0)                   # noqa: E731
+            put = lambda a, v, back=0: a.index_copy_(0, self._tidx[back], v.reshape((1,) + a.shape[1:]).to(a.dtype))   # noqa: E731
+        lw, x, iv, suff_stats, a = self.step(rand, time, prev(lw_trace), prev(state_trace), [prev(int_var_trace[i]) for i in range(self.N_int)], suff_stats)
+        put(state_trace, x)
+        put(lw_trace, lw)
+        put(anc_trace, a, 1)
+        w = torch.softmax(lw, dim=0)
+        for i in range(self.N_int):
+            put(int_var_trace[i], iv[i])
+            for j, v in enumerate(self._weighted(suff_stats[i], w)):
+                put(sst[i][j], v)                                                          # :445-457
+        return suff_stats
+
+    def _graphed_loop(self, rand, traces, suff_stats, T):
+        """The loop :418-457 as ONE captured HIP graph replayed for t = 2 .. T-1: a step is ~60 small launches, which at the
+        reference's N = 200 is pure launch latency.  The time index lives on the device (random-number counters: pgas_m_set_time_source;
+        rows of inputs / observations / traces: index_select / index_copy_ on it) and is incremented inside the graph; the
+        per-particle statistics are carried in static buffers.  Same kernels in the same order as the eager loop: identical results."""
+        dev = self.device
+        suff_stats = self._loop_body(rand, 1, traces, suff_stats)          # t = 1 eagerly: lazy allocations, library warm-up
+        if T <= 2:
+            return suff_stats
+        t32 = torch.full((1,), 2, dtype=torch.int32, device=dev)          # what the random-number kernels read
+        self._tidx = (torch.full((1,), 2, dtype=torch.int64, device=dev), torch.full((1,), 1, dtype=torch.int64, device=dev))
+        carried = tuple(tuple(t.clone() for t in s) for s in suff_stats)
+        self.ops.set_time_source(t32)
+        try:
+            def body():
+                new = self._loop_body(rand, 0, traces, carried)           # `time` is ignored in graph mode
+                for i in range(self.N_int):
+                    for dst, src in zip(carried[i], new[i]):
+                        dst.copy_(src.reshape(dst.shape))
+                t32.add_(1)
+                self._tidx[0].add_(1)
+                self._tidx[1].add_(1)
+
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                body()                                                     # t = 2 eagerly on the side stream (capture warm-up)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            if T > 3:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    body()
+                # the capture itself does not execute: t = 3 .. T-1 are replays
+                for _ in range(3, T):
+                    graph.replay()
+            torch.cuda.current_stream(dev).synchronize()
+        finally:
+            self.ops.set_time_source(None)
+            self._tidx = None
+        return carried
+
+    def __call__(self, key, use_graph=None):
+        """use_graph: capture the filter step in a HIP graph and replay it (default: when N_samples <= 4096, the launch-latency-bound
+        regime; the statistics are then copied once per step, which costs nothing there and 14 GB of traffic per step at N = 2^20)."""
         rand = self._rand(key)
         state_trace, int_var_trace, sst, lw_trace, anc_trace, suff_stats = self._init_algorithm(rand)
         T = self.observations.shape[0]
-        for time in range(1, T):
-            lw, x, iv, suff_stats, a = self.step(rand, time, lw_trace[time - 1], state_trace[time - 1],
-                                                 [int_var_trace[i][time - 1] for i in range(self.N_int)], suff_stats)
-            state_trace[time], lw_trace[time], anc_trace[time - 1] = x, lw, a
-            w = torch.softmax(lw, dim=0)
-            for i in range(self.N_int):
-                int_var_trace[i][time] = iv[i]
-                for j, v in enumerate(self._weighted(suff_stats[i], w)):
-                    sst[i][j][time] = v.reshape(sst[i][j][time].shape)                     # :445-457
+        traces = (state_trace, int_var_trace, sst, lw_trace, anc_trace)
+        if use_graph is None:
+            use_graph = self.N_samples <= 4096 and isinstance(rand, DeviceRand)
+        if use_graph and T > 1:
+            suff_stats = self._graphed_loop(rand, traces, suff_stats, T)
+        else:
+            for time in range(1, T):
+                suff_stats = self._loop_body(rand, time, traces, suff_stats)
         self.ops.check()
         weights_trace = torch.softmax(lw_trace, dim=1)                                     # :460
         obs_trace = torch.stack([self.SSM.output_mdl(state_trace[t], self.inputs[t], *[v[t] for v in int_var_trace]).reshape(self.N_samples, -1)

@@ -39,7 +39,7 @@ EXPORTS = [
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
     "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
-    "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_chi2", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
+    "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_chi2", "pgas_m_set_time_source", "pgas_m_rng_uniform_dev", "pgas_systematic_resample_dev", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)   # pgas_allgather_fn (include/pgas_hip.h)
@@ -124,6 +124,12 @@ def load():
     L.pgas_m_rng_normal.argtypes = [vp, u64, u32, u32, i64, i64, i32, vp, vp]
     L.pgas_m_rng_student_t.restype = C.c_int
     L.pgas_m_rng_student_t.argtypes = [vp, u64, u32, u32, i64, i64, vp, vp, vp]
+    L.pgas_m_set_time_source.restype = C.c_int
+    L.pgas_m_set_time_source.argtypes = [vp, vp]
+    L.pgas_m_rng_uniform_dev.restype = C.c_int
+    L.pgas_m_rng_uniform_dev.argtypes = [vp, u64, u32, u32, vp, vp]
+    L.pgas_systematic_resample_dev.restype = C.c_int
+    L.pgas_systematic_resample_dev.argtypes = [vp, vp, vp, vp, vp]
     L.pgas_m_rng_chi2.restype = C.c_int
     L.pgas_m_rng_chi2.argtypes = [vp, u64, u32, u32, i64, i64, vp, vp, vp]
     L.pgas_m_mniw_solve.restype = C.c_int
@@ -338,9 +344,13 @@ class Engine:
         return cls._utility[key]
 
     def systematic_resample(self, u, logw):
+        """u: a float, or a device tensor holding the uniform (read at execution time: graph-captured steps)."""
         lw = self._dev(logw, shape=(self.N,))
         idx = torch.empty(self.N, dtype=torch.int32, device=self.device)
-        self._chk(self.lib.pgas_systematic_resample(self._h, float(u), lw.data_ptr(), idx.data_ptr(), self._stream()), "pgas_systematic_resample")
+        if isinstance(u, torch.Tensor):
+            self._chk(self.lib.pgas_systematic_resample_dev(self._h, u.data_ptr(), lw.data_ptr(), idx.data_ptr(), self._stream()), "pgas_systematic_resample_dev")
+        else:
+            self._chk(self.lib.pgas_systematic_resample(self._h, float(u), lw.data_ptr(), idx.data_ptr(), self._stream()), "pgas_systematic_resample")
         return idx
 
     def reconstruct_trajectory(self, particles, ancestry, idx):
@@ -492,6 +502,17 @@ class MarginalOps:
 
     def uniform(self, seed, stream, t):
         return float(self.lib.pgas_m_rng_uniform(int(seed), int(stream), int(t)))
+
+    def set_time_source(self, t_dev):
+        """t_dev: a uint32-sized device tensor (int32 works) the random-number kernels read their time index from, or None."""
+        self._t_dev = t_dev   # keep it alive
+        self.eng._chk(self.lib.pgas_m_set_time_source(self.eng._h, 0 if t_dev is None else t_dev.data_ptr()), "pgas_m_set_time_source")
+
+    def uniform_dev(self, seed, stream, t):
+        """The same uniform as `uniform`, produced on the device into a one-element tensor (time index from the time source if set)."""
+        out = torch.empty(1, dtype=torch.float64, device=self.device)
+        self.eng._chk(self.lib.pgas_m_rng_uniform_dev(self.eng._h, int(seed), int(stream), int(t), out.data_ptr(), self.eng._stream()), "pgas_m_rng_uniform_dev")
+        return out
 
     def normal(self, seed, stream, t, ncol):
         out = self._vec(cols=int(ncol))

@@ -209,6 +209,7 @@ struct pgas_ctx {
     size_t syrk_ws_bytes = 0;
     int syrk_splits = 0;           // 0 = automatic
     bool peer_access_tried = false;
+    const uint32_t* t_dev = nullptr;   // pgas_m_set_time_source: time index of the marginalised family's random-number kernels, device-resident
     int max_lead = 0;              // PGAS_OPT_MAX_LEAD
     std::vector<hipEvent_t> ev_bdone;
     // optional per-launch timing of the dominant kernel (pgas_set_profiling)
@@ -939,9 +940,7 @@ int pgas_debug_stamps(unsigned long long* out /* 2048*16 */) {
 
 /* systematic_SISR (src/Filtering.py:6-37) on log-weights: idx[i] = first k with W_k >= (u + i)/N, W the canonical CDF of
  * softmax(logw).  Uses the context's scan scratch; logw_dev (N), idx_dev (N) int32. */
-int pgas_systematic_resample(pgas_ctx* c, double u, const double* logw_dev, int32_t* idx_dev, void* stream) {
-    if (!c) return PGAS_E_ARG;
-    if (!logw_dev || !idx_dev || !(u >= 0.0 && u < 1.0)) FAIL(c, PGAS_E_ARG, "pgas_systematic_resample: bad argument");
+static int systematic_impl(pgas_ctx* c, double u, const double* u_dev, const double* logw_dev, int32_t* idx_dev, void* stream) {
     if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_systematic_resample: not available on a shard context");
     DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
@@ -951,9 +950,21 @@ int pgas_systematic_resample(pgas_ctx* c, double u, const double* logw_dev, int3
     KCHK(c, "k_segscan");
     int rc = launch_groups(c, c->sb[0], 1, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_systematic, dim3(md.nseg), dim3(PG_BLK), 0, st, md, u, c->sb[0], peers_for(c, 0), idx_dev);
+    hipLaunchKernelGGL(k_systematic, dim3(md.nseg), dim3(PG_BLK), 0, st, md, u, u_dev, c->sb[0], peers_for(c, 0), idx_dev);
     KCHK(c, "k_systematic");
     return PGAS_OK;
+}
+
+int pgas_systematic_resample(pgas_ctx* c, double u, const double* logw_dev, int32_t* idx_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!logw_dev || !idx_dev || !(u >= 0.0 && u < 1.0)) FAIL(c, PGAS_E_ARG, "pgas_systematic_resample: bad argument");
+    return systematic_impl(c, u, nullptr, logw_dev, idx_dev, stream);
+}
+
+int pgas_systematic_resample_dev(pgas_ctx* c, const double* u_dev, const double* logw_dev, int32_t* idx_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!u_dev || !logw_dev || !idx_dev) FAIL(c, PGAS_E_ARG, "pgas_systematic_resample_dev: NULL argument");
+    return systematic_impl(c, 0.0, u_dev, logw_dev, idx_dev, stream);
 }
 
 /* reconstruct_trajectory (src/Filtering.py:40-55): x_dev (T,N,nx), anc_dev (T-1,N) int32 with anc[i][j] = index at time i of the
@@ -1297,8 +1308,23 @@ int pgas_m_rng_normal(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t, i
     if (!out || n < 0 || ncol < 1 || ncol > 8) FAIL(c, PGAS_E_ARG, "pgas_m_rng_normal: bad argument (n = %lld, ncol = %d)", (long long)n, ncol);
     if (n == 0) return PGAS_OK;
     DeviceGuard guard(c->device);
-    hipLaunchKernelGGL(k_rng_normal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, p0, n, ncol, out);
+    hipLaunchKernelGGL(k_rng_normal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, c->t_dev, p0, n, ncol, out);
     KCHK(c, "k_rng_normal");
+    return PGAS_OK;
+}
+
+int pgas_m_set_time_source(pgas_ctx* c, const uint32_t* t_dev) {
+    if (!c) return PGAS_E_ARG;
+    c->t_dev = t_dev;
+    return PGAS_OK;
+}
+
+int pgas_m_rng_uniform_dev(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t, double* out_dev, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!out_dev) FAIL(c, PGAS_E_ARG, "pgas_m_rng_uniform_dev: NULL argument");
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(k_rng_uniform_dev, dim3(1), dim3(64), 0, (hipStream_t)sh, seed, stream, t, c->t_dev, out_dev);
+    KCHK(c, "k_rng_uniform_dev");
     return PGAS_OK;
 }
 
@@ -1307,7 +1333,7 @@ int pgas_m_rng_student_t(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t
     if (!out || !nu || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_rng_student_t: bad argument");
     if (n == 0) return PGAS_OK;
     DeviceGuard guard(c->device);
-    hipLaunchKernelGGL(k_rng_student_t, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, p0, n, nu, out);
+    hipLaunchKernelGGL(k_rng_student_t, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, c->t_dev, p0, n, nu, out);
     KCHK(c, "k_rng_student_t");
     return PGAS_OK;
 }

@@ -13,23 +13,32 @@
 
 #include "pgas_kernels.hip.h"
 
-__global__ __launch_bounds__(256) void k_rng_normal(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, int ncol,
-                                                     double* __restrict__ out) {
+// t_dev (nullable): the time index of the Philox counters read from device memory instead of the argument -- what lets a whole
+// filter step be captured in a graph and replayed for every t (pgas_m_set_time_source)
+__global__ __launch_bounds__(256) void k_rng_normal(uint64_t seed, uint32_t stream, uint32_t t, const uint32_t* __restrict__ t_dev, int64_t p0,
+                                                     int64_t n, int ncol, double* __restrict__ out) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
+    if (t_dev) t = *t_dev;
     double z[8];
     pgas_rng_normals(seed, stream, t, (uint64_t)(p0 + p), ncol, z);
     for (int k = 0; k < ncol; ++k) out[p * ncol + k] = z[k];
 }
 
-__global__ __launch_bounds__(256) void k_rng_student_t(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n,
-                                                        const double* __restrict__ nu, double* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_rng_student_t(uint64_t seed, uint32_t stream, uint32_t t, const uint32_t* __restrict__ t_dev, int64_t p0,
+                                                        int64_t n, const double* __restrict__ nu, double* __restrict__ out) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
+    if (t_dev) t = *t_dev;
     out[p] = pgas_rng_student_t(seed, stream, t, (uint64_t)(p0 + p), nu[p]);
 }
 
 // chi^2(nu_p) = 2 Gamma(nu_p / 2): the Bartlett diagonal of PGAS.sample_params (src/PGAS.py:323-327), drawn where it is consumed
+// one uniform of (seed, stream, t) into device memory: the u of systematic resampling when t comes from t_dev
+__global__ void k_rng_uniform_dev(uint64_t seed, uint32_t stream, uint32_t t, const uint32_t* __restrict__ t_dev, double* __restrict__ out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[0] = pgas_rng_uniform(seed, stream, t_dev ? *t_dev : t);
+}
+
 __global__ __launch_bounds__(256) void k_rng_chi2(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* __restrict__ nu,
                                                    double* __restrict__ out) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -719,10 +719,11 @@ __global__ __launch_bounds__(PG_BLK) void k_back_corrected(DevModel md, TransPar
 }
 
 // systematic_SISR (src/Filtering.py:6-37) on a weight vector whose segment scans (k_segscan) and group records (k_groups) are in sb
-__global__ __launch_bounds__(PG_BLK) void k_systematic(DevModel md, double u, ScanBufs sb, Peers pr, int32_t* __restrict__ idx_out) {
+__global__ __launch_bounds__(PG_BLK) void k_systematic(DevModel md, double u, const double* __restrict__ u_dev, ScanBufs sb, Peers pr,
+                                                      int32_t* __restrict__ idx_out) {
     __shared__ WinSmemT<false> sm;
     int anc[PG_PPT];
-    resample_slots<false>(md, sm, u, sb, pr, blockIdx.x, idx_out, anc, -1);
+    resample_slots<false>(md, sm, u_dev ? u_dev[0] : u, sb, pr, blockIdx.x, idx_out, anc, -1);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -156,6 +156,8 @@ int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
  * from `key` (:19); weights are passed as log-weights (log 0 = -inf allowed, negative weights have no logarithm: the
  * reference's clip at :23 is the caller's clamp).  reconstruct_trajectory(Particles, ancestry, idx) (:40-55). */
 int pgas_systematic_resample(pgas_ctx* ctx, double u, const double* logw_dev, int32_t* idx_dev, void* stream);
+/* The same with the uniform u read from device memory at execution time (graph-captured filter steps, include/pgas_marginal.h). */
+int pgas_systematic_resample_dev(pgas_ctx* ctx, const double* u_dev, const double* logw_dev, int32_t* idx_dev, void* stream);
 int pgas_reconstruct_trajectory(pgas_ctx* ctx, const double* x_dev, const int32_t* anc_dev, int32_t T, int32_t nx, int64_t idx,
                                 double* traj_dev, void* stream);
 

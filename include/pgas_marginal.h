@@ -28,6 +28,13 @@ int pgas_m_rng_normal(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t,
                       double* out_dev, void* stream_handle);
 
 /* out (n): Student-t(nu[p]) variates (z / sqrt(chi2_nu / nu), Marsaglia-Tsang gamma sampler on the same Philox streams). */
+/* Device-resident time index.  With t_dev != NULL every later pgas_m_rng_normal / _student_t / _uniform_dev call of this context takes
+ * the time index of its Philox counters from *t_dev at execution time (the `t` argument is ignored): a filter step captured once in a HIP
+ * graph can then be replayed for every t (reference loop src/Algorithm1.py:418-457).  NULL restores the argument.  t_dev must stay valid. */
+int pgas_m_set_time_source(pgas_ctx* ctx, const uint32_t* t_dev);
+/* out_dev[0] = the uniform pgas_m_rng_uniform(seed, stream, t) returns on the host, written on the device (t from the time source if set) */
+int pgas_m_rng_uniform_dev(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t, double* out_dev, void* stream_handle);
+
 int pgas_m_rng_student_t(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu_dev,
                          double* out_dev, void* stream_handle);
 
