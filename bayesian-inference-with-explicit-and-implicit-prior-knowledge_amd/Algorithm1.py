@@ -211,24 +211,38 @@ class Algorithm1:
         return suff_stats
 
     def _graphed_loop(self, rand, traces, suff_stats, T):
-        """The loop :418-457 as ONE captured HIP graph replayed for t = 2 .. T-1: a step is ~60 small launches, which at the
-        reference's N = 200 is pure launch latency.  The time index lives on the device (random-number counters: pgas_m_set_time_source;
-        rows of inputs / observations / traces: index_select / index_copy_ on it) and is incremented inside the graph; the
-        per-particle statistics are carried in static buffers.  Same kernels in the same order as the eager loop: identical results."""
+        return self._replay(T, suff_stats, lambda time, carried: self._loop_body(rand, time, traces, carried))
+
+    def _row(self, a, time):
+        """a[time]; in graph mode the row is selected on the device from the time tensor."""
+        return a[time] if self._tidx is None else a.index_select(0, self._tidx[0]).squeeze(0)
+
+    def _replay(self, T, carried, body):
+        """Run `carried = body(time, carried)` for time = 1 .. T-1 as ONE captured HIP graph replayed for t = 3 .. T-1: a step is ~100
+        small launches, which at the reference's N = 200 is pure launch latency.  The time index lives on the device (random-number
+        counters: pgas_m_set_time_source; rows of inputs / observations / traces: index_select / index_copy_ on it) and is incremented
+        inside the graph; `carried` (a nested tuple of tensors: the per-particle statistics, ...) lives in static buffers.  Same kernels
+        in the same order as the eager loop: identical results."""
         dev = self.device
-        suff_stats = self._loop_body(rand, 1, traces, suff_stats)          # t = 1 eagerly: lazy allocations, library warm-up
+
+        def flat(x):
+            return [x] if isinstance(x, torch.Tensor) else [t for y in x for t in flat(y)]
+
+        def clone(x):
+            return x.clone() if isinstance(x, torch.Tensor) else tuple(clone(y) for y in x)
+
+        carried = body(1, carried)                                         # t = 1 eagerly: lazy allocations, library warm-up
         if T <= 2:
-            return suff_stats
+            return carried
         t32 = torch.full((1,), 2, dtype=torch.int32, device=dev)          # what the random-number kernels read
         self._tidx = (torch.full((1,), 2, dtype=torch.int64, device=dev), torch.full((1,), 1, dtype=torch.int64, device=dev))
-        carried = tuple(tuple(t.clone() for t in s) for s in suff_stats)
+        carried = clone(carried)
         self.ops.set_time_source(t32)
         try:
-            def body():
-                new = self._loop_body(rand, 0, traces, carried)           # `time` is ignored in graph mode
-                for i in range(self.N_int):
-                    for dst, src in zip(carried[i], new[i]):
-                        dst.copy_(src.reshape(dst.shape))
+            def one():
+                new = body(0, carried)                                     # `time` is ignored in graph mode
+                for dst, src in zip(flat(carried), flat(new)):
+                    dst.copy_(src.reshape(dst.shape))
                 t32.add_(1)
                 self._tidx[0].add_(1)
                 self._tidx[1].add_(1)
@@ -236,14 +250,17 @@ class Algorithm1:
             side = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(side):
-                body()                                                     # t = 2 eagerly on the side stream (capture warm-up)
+                one()                                                      # t = 2 eagerly on a side stream (capture warm-up)
             torch.cuda.current_stream(dev).wait_stream(side)
             if T > 3:
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    body()
-                # the capture itself does not execute: t = 3 .. T-1 are replays
-                for _ in range(3, T):
+                try:
+                    with torch.cuda.graph(graph):
+                        one()
+                except Exception as e:   # noqa: BLE001
+                    raise RuntimeError("the filter step could not be captured in a HIP graph (a model callable that synchronises with the host, "
+                                       "e.g. .item() / .cpu() / a Python scalar assigned into a tensor?); call with use_graph=False") from e
+                for _ in range(3, T):                                      # the capture itself does not execute
                     graph.replay()
             torch.cuda.current_stream(dev).synchronize()
         finally:

@@ -46,9 +46,10 @@ class Algorithm3(Algorithm1):
         ref_int_var = [(_t(v, dev) if not isinstance(v, torch.Tensor) else v).reshape(-1) for v in ref_int_var]
         ref_suff_stats = [tuple((_t(r, dev) if not isinstance(r, torch.Tensor) else r) for r in rs) for rs in ref_suff_stats]
         aux_state, aux_int_var, factors = self._generate_auxiliary_states(state, time, int_var, suff_stats)      # :66-68
-        ll_aux = self.SSM.log_likelihood(self.observations[time], aux_state, self.inputs[time], *aux_int_var)     # :71-84
+        ll_aux = self.SSM.log_likelihood(self._obs(time), aux_state, self._inp(time), *aux_int_var)     # :71-84
         lw_aux = ll_aux + log_weights
-        a = self.ops.systematic_resample(rand.uniform(STREAM_RESAMPLE, time), lw_aux.contiguous())                # :85-90
+        graphed = self._tidx is not None   # graph replay: the uniforms are produced on the device from the device-resident time index
+        a = self.ops.systematic_resample(rand.uniform_dev(STREAM_RESAMPLE, time) if graphed else rand.uniform(STREAM_RESAMPLE, time), lw_aux.contiguous())   # :85-90
         if self.SSM.is_deterministic:
             # with process_noise == 0 (src/Toy_Example.py:66) the Gaussian of :109-116 is singular: the reference's weights are NaN and
             # its index implementation-defined; here the reference particle keeps its own ancestor
@@ -63,10 +64,13 @@ class Algorithm3(Algorithm1):
             e = (ref_state.reshape(1, -1) - aux_state) @ self._Qc[0]                       # :109-116
             h_x = self._Qc[1] - 0.5 * (e * e).sum(dim=1)
             w_anc = torch.softmax(lw_aux + g + h_x, dim=0)                                 # :117-118
-            u = torch.full((1,), rand.uniform(STREAM_ANCESTOR, time), dtype=torch.float64, device=dev)
+            u = rand.uniform_dev(STREAM_ANCESTOR, time) if graphed else torch.full((1,), rand.uniform(STREAM_ANCESTOR, time), dtype=torch.float64, device=dev)
             ref_idx = torch.clamp(torch.searchsorted(torch.cumsum(w_anc, 0), u)[0], max=N - 1)     # stays on the device: no host round trip
         a = a.clone()
-        a[-1] = ref_idx                                                                    # :121-127 (clip: SURVEY Q4)
+        if isinstance(ref_idx, int):
+            a[-1:].fill_(ref_idx)                                                          # (a fill, not a host-to-device copy: capturable)
+        else:
+            a[-1] = ref_idx                                                                # :121-127 (clip: SURVEY Q4)
         new_state = self._draw_states(rand, time, state, int_var, a)                       # :130-133
         new_state[-1] = ref_state                                                          # :134
         new_int_var, new_basis = self._draw_int_vars(rand, time, new_state, suff_stats, a, factors)              # :139-148
@@ -76,15 +80,15 @@ class Algorithm3(Algorithm1):
                           for i in range(self.N_int))                                      # :155-162
         new_ref = []
         for i in range(self.N_int):                                                        # :165-176
-            rb = self.basis_fcn[i](ref_state.reshape(1, -1), self.inputs[time]).reshape(-1)
+            rb = self.basis_fcn[i](ref_state.reshape(1, -1), self._inp(time)).reshape(-1)
             xi = ref_int_var[i].reshape(())
             R0, R1, R2, R3 = ref_suff_stats[i]
             new_ref.append((R0.reshape(-1) - rb * xi, R1 - rb[:, None] * rb[None, :], R2.reshape(()) - xi * xi, R3.reshape(()) - 1.0))
-        new_lw = self.SSM.log_likelihood(self.observations[time], new_state, self.inputs[time], *new_int_var) - ll_aux[a.long()]   # :179-189
+        new_lw = self.SSM.log_likelihood(self._obs(time), new_state, self._inp(time), *new_int_var) - ll_aux[a.long()]   # :179-189
         return new_lw, new_state, new_int_var, new_stats, a, tuple(new_ref)
 
     # ------------------------------------------------------------------------------------------------------ :199-303
-    def __call__(self, key, ref_state, ref_int_var, ref_suff_stats, return_traces=False):
+    def __call__(self, key, ref_state, ref_int_var, ref_suff_stats, return_traces=False, use_graph=None):
         rand, dev = self._rand(key), self.device
         state_trace, int_var_trace, _, lw_trace, anc_trace, suff_stats = self._init_algorithm(rand)
         T = self.observations.shape[0]
@@ -103,13 +107,29 @@ class Algorithm3(Algorithm1):
                 suff_stats[i][j][-1] = iT[j]                                               # :228-231
             ref_ss[i] = tuple(ref_ss[i][j] - iT[j] for j in range(4))                      # :235-246
         suff_stats = tuple(tuple(s) for s in suff_stats)
-        for time in range(1, T):                                                           # :251-290
-            lw, x, iv, suff_stats, a, ref_ss = self.step(rand, time, lw_trace[time - 1], state_trace[time - 1],
-                                                         [int_var_trace[i][time - 1] for i in range(self.N_int)], suff_stats,
-                                                         ref_state[time], [ref_int_var[i][time] for i in range(self.N_int)], ref_ss)
-            state_trace[time], lw_trace[time], anc_trace[time - 1] = x, lw, a
+        def body(time, carried):                                                           # one iteration of :251-290
+            stats, rss = carried
+            graphed = self._tidx is not None
+            prev = (lambda a: a.index_select(0, self._tidx[1]).squeeze(0)) if graphed else (lambda a: a[time - 1])
+            put = (lambda a, v, back=0: a.index_copy_(0, self._tidx[back], v.reshape((1,) + a.shape[1:]).to(a.dtype))) if graphed else \
+                (lambda a, v, back=0: a.__setitem__(time - back, v.reshape(a.shape[1:])))
+            lw, x, iv, stats, a, rss = self.step(rand, time, prev(lw_trace), prev(state_trace), [prev(int_var_trace[i]) for i in range(self.N_int)],
+                                                 stats, self._row(ref_state, time), [self._row(ref_int_var[i], time) for i in range(self.N_int)], rss)
+            put(state_trace, x)
+            put(lw_trace, lw)
+            put(anc_trace, a, 1)
             for i in range(self.N_int):
-                int_var_trace[i][time] = iv[i]
+                put(int_var_trace[i], iv[i])
+            return stats, tuple(tuple(r) for r in rss)
+
+        carried = (suff_stats, tuple(tuple(r) for r in ref_ss))
+        if use_graph is None:
+            use_graph = self.N_samples <= 4096 and hasattr(rand, "uniform_dev")
+        if use_graph and T > 1:
+            carried = self._replay(T, carried, body)                                       # Algorithm1._replay: one captured step, replayed
+        else:
+            for time in range(1, T):
+                carried = body(time, carried)
         self.ops.check()
         w = torch.softmax(lw_trace[-1], dim=0)                                             # :293
         u = torch.tensor([rand.uniform(STREAM_FINAL, 0)], dtype=torch.float64, device=dev)

@@ -192,6 +192,21 @@ def test_algorithm3_matches_restatement(name, N):
         _close(gi[i], ivt[i], f"interface-variable trajectory {i}")
 
 
+@pytest.mark.parametrize("name", ["smo", "toy", "vehicle"])
+def test_algorithm3_graph_replay_equals_eager_loop(name):
+    """The conditional filter's loop (src/Algorithm3.py:251-290) captured once and replayed: traces, trajectory and final index equal
+    the eager loop's bit for bit (reference rows, reference statistics and both uniforms are addressed on the device)."""
+    pb = _problem(name, T=12)
+    ref_x, ref_iv = pb.X_true, list(pb.int_var_true)
+    ref_stats = mo.trajectory_stats(marginal_oracle(pb, 200, "Algorithm3"), ref_x, ref_iv)
+    outs = []
+    for mode in (False, True):
+        gt, gi, gtr = _device_alg(pb, 200, "Algorithm3")(SEED, ref_x, ref_iv, ref_stats, return_traces=True, use_graph=mode)
+        outs.append([gt, gtr["state_trace"], gtr["ancestor_trace"], gtr["log_weights"]] + list(gi) + [torch.tensor(gtr["idx"])])
+    for k, (a, b) in enumerate(zip(*outs)):
+        assert a.shape == b.shape and torch.equal(a.cpu(), b.cpu()), f"output {k} differs between the eager loop and the graph replay"
+
+
 @pytest.mark.parametrize("name", ["smo", "vehicle"])
 def test_algorithm2_matches_restatement(name):
     """Whole Particle-Gibbs chains (Algorithm2 over Algorithm3): the device mirror splits its key once per iteration

@@ -28,3 +28,20 @@ for mode in (False, True):
             stats = alg._loop_body(rand, t, traces, stats)
     torch.cuda.synchronize(); dt = time.perf_counter() - t0
     print(f"loop only, use_graph={mode}: {1e3 * dt / (T - 1):.3f} ms per step", flush=True)
+# Algorithm2 (Particle Gibbs over the conditional filter): seconds per Gibbs iteration, graph replay against the eager loop
+import numpy as np
+K = 3
+common = dict(N_samples=N, N_iterations=K, observations=pb.observations, inputs=pb.inputs, SSM=ssm, init_state_mean=pb.init_state_mean,
+              init_state_cov=pb.init_state_cov, init_int_var_mean=pb.init_int_var_mean, init_int_var_cov=pb.init_int_var_cov,
+              GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn())
+a2 = pgas_amd.Algorithm2(**common)
+for mode in (True, False):
+    c3 = a2.cSMC
+    orig = type(c3).__call__
+    type(c3).__call__ = lambda self, *a, _o=orig, _m=mode, **k: _o(self, *a, use_graph=_m, **k)
+    try:
+        a2(1, pb.X_true, list(pb.int_var_true)); torch.cuda.synchronize()
+        t0 = time.perf_counter(); a2(12345678, pb.X_true, list(pb.int_var_true)); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    finally:
+        type(c3).__call__ = orig
+    print(f"Algorithm2 N={N} T={T} K={K} use_graph={mode}: {dt / (K - 1):.3f} s per Gibbs iteration", flush=True)
