@@ -4,7 +4,8 @@ import torch
 sys.path.insert(0, ".")
 import pgas_amd
 from pgas_amd import experiments
-N, T = 1 << 20, 2000
+import os
+N, T = int(os.environ.get("N", 1 << 20)), int(os.environ.get("T", 2000))
 pb = experiments.smo_pgas(T=T)
 pg = pgas_amd.PGAS(N, 2, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior, pb.basis_fcn)
 ref = torch.as_tensor(pb.X_true, device=pg.cSMC.engine.device)
