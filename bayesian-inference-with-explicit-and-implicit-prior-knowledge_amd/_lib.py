@@ -38,7 +38,7 @@ EXPORTS = [
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
-    "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
+    "pgas_hip_runtime_version", "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
     "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_chi2", "pgas_m_set_time_source", "pgas_m_rng_uniform_dev", "pgas_systematic_resample_dev", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
 ]
 
@@ -115,6 +115,8 @@ def load():
     L.pgas_get_launch_info.argtypes = [vp, C.POINTER(i32)]
     L.pgas_ipc_export.restype = C.c_int
     L.pgas_ipc_export.argtypes = [vp, i32, C.c_char_p]
+    L.pgas_hip_runtime_version.restype = C.c_int32
+    L.pgas_hip_runtime_version.argtypes = []
     L.pgas_ipc_open.restype = C.c_int
     L.pgas_ipc_open.argtypes = [vp, C.c_char_p, C.POINTER(vp)]
     u32 = C.c_uint32

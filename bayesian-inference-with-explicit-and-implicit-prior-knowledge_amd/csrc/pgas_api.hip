@@ -1220,6 +1220,11 @@ int pgas_shard_probe_collective(pgas_ctx* c, int32_t reps, void* stream) {
 
 /* xGMI / IPC plumbing for peers in OTHER processes: export a 64-byte handle of one of this context's buffers
  * (index as in pgas_shard_buffers, 0..6) and map a peer's handle into this process. */
+int32_t pgas_hip_runtime_version(void) {
+    int v = 0;
+    return hipRuntimeGetVersion(&v) == hipSuccess ? v : -1;
+}
+
 int pgas_ipc_export(pgas_ctx* c, int32_t which, void* handle64) {
     if (!c) return PGAS_E_ARG;
     void* bufs[17]; int64_t sz[3];

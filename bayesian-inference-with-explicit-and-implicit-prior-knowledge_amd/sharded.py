@@ -94,6 +94,18 @@ class DistGroup:
         self.dist, self.group, self.shards = dist, group, [shard]
         self.library_loop = True
         rank, world = dist.get_rank(group), dist.get_world_size(group)
+        # The HIP 7.0 runtime PyTorch 2.10+rocm7.0 bundles hangs in hipIpcOpenMemHandle for allocations of 2 GiB and more (measured:
+        # 2047 MiB opens in 0.4 ms, 2048 MiB never returns; ROCm 7.2's opens 34 GB in 0.3 ms).  Refuse on every rank rather than hang:
+        # the cure is the system runtime under the same process (LD_PRELOAD, what bench.py does for its multi-rank runs).
+        def ipc_hazard():
+            ver = int(shard.eng.lib.pgas_hip_runtime_version())
+            biggest = 8 * shard.T * shard.Nl * max(shard.eng.nx, 1)   # x_trace; la / h / ln rows are 8 T N_l bytes each
+            if world > 1 and 0 <= ver < 70200000 and biggest >= (1 << 31):
+                raise PgasError(f"the HIP runtime in this process (version {ver}) hangs in hipIpcOpenMemHandle on allocations >= 2 GiB and the "
+                                f"state trace of this shard has {biggest / 2**30:.1f} GiB: start the process with "
+                                "LD_PRELOAD=/opt/rocm/lib/libamdhip64.so:/opt/rocm/lib/libhsa-runtime64.so (ROCm >= 7.2)")
+
+        agree_on(dist, group, "HIP IPC of buffers above 2 GiB", ipc_hazard)
         handles = [shard.eng.ipc_export(k) for k in range(7)]
         everyone = [None] * world
         dist.all_gather_object(everyone, handles, group=group)

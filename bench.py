@@ -209,6 +209,23 @@ def respawn_under_torchrun(args):
     raise SystemExit(subprocess.call(cmd))
 
 
+SYSTEM_HIP = ("/opt/rocm/lib/libamdhip64.so", "/opt/rocm/lib/libhsa-runtime64.so")
+
+
+def use_system_hip_runtime(args):
+    """Multi-rank runs map their peers' trace buffers (tens of GB each) with hipIpcOpenMemHandle, and the HIP 7.0 runtime bundled with
+    PyTorch 2.10+rocm7.0 hangs in that call for allocations >= 2 GiB (tools/ipc_probe.py).  ROCm 7.2's runtime does
+    not: restart this rank with it preloaded -- an exec BEFORE anything has touched the GPU (torch is not even imported yet)."""
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1 or ("WORLD_SIZE" in os.environ and args.mode == "sharded")
+    if not multi or os.environ.get("PGAS_SYSTEM_HIP") or os.environ.get("PGAS_NO_PRELOAD") or not all(os.path.exists(p) for p in SYSTEM_HIP):
+        return
+    env = dict(os.environ)
+    env["PGAS_SYSTEM_HIP"] = "1"
+    env["LD_PRELOAD"] = ":".join(list(SYSTEM_HIP) + [p for p in env.get("LD_PRELOAD", "").split(":") if p])
+    sys.stderr.flush()
+    os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +253,7 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
+    use_system_hip_runtime(args)
 
     import torch
     import torch.distributed as dist
@@ -243,17 +261,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
+    if world != args.gpus and not os.environ.get("PGAS_BENCH_REHEARSE"):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or without a launcher)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    # PGAS_BENCH_REHEARSE=1 (development aid, one-GPU boxes): every rank uses device 0 and the collectives run over gloo with the
+    # library's host-callback all-gather -- the multi-rank code path of this script (IPC peer mappings between processes included) with
+    # everything but RCCL and xGMI.  The numbers of such a run mean nothing.
+    rehearse = os.environ.get("PGAS_BENCH_REHEARSE", "0") == "1"
+    if rehearse:
+        local_rank = 0
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("PGAS_BENCH_REHEARSE_DUMP_S", "90")), repeat=True, file=sys.stderr)   # where is a stalled rank?
     torch.cuda.set_device(local_rank)
     # a launcher (torch.distributed.run) with ONE rank and an explicit --mode sharded runs the sharded code path with world = 1:
     # the same kernels and one-rank RCCL collectives, no wire time -- the figure to hold against the unsharded sweep
     use_dist = world > 1 or ("WORLD_SIZE" in os.environ and args.mode == "sharded")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import pgas_amd
     from pgas_amd import experiments
@@ -283,6 +312,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def mark(msg):
+        if rehearse:
+            print(f"[rehearse rank {rank}] {msg}", file=sys.stderr, flush=True)
+
+    mark("model and parameters ready")
     grp, shard_fallback = None, None
     if sharded_mode:
         from pgas_amd import sharded
@@ -327,9 +361,12 @@ def main():
         else:
             pg.cSMC(sd, ref, A, S)
 
+    mark("sharded group ready" if grp is not None else "engine ready")
     for w in range(args.warmup):
         one_sweep(seed + 1000 + w)
+        mark(f"warm-up sweep {w} enqueued")
     barrier()
+    mark("warm-up done")
     t0 = time.perf_counter()
     prof_n, prof_ms, prop_n, prop_ms = 0, 0.0, 0, 0.0
     for k in range(args.steps):
@@ -357,11 +394,13 @@ def main():
         "metric": "particle-steps/sec (N x (T-1) / wall), " + {"smo": "SingleMassOscillator", "vehicle": "Vehicle", "emps": "EMPS"}[args.workload] + " PGAS conditional-SMC sweep",
         "value": units / dt, "unit": "particle-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic" + (" -- REHEARSAL (PGAS_BENCH_REHEARSE=1): all ranks on one device, gloo collectives; not a measurement" if rehearse else ""),
         "config": {
             "workload": f"{wl_name}, N={N} particles/GPU" + (f" ({N * world} in all)" if sharded_mode else "") + f", T={T}, fp64",
             "particles_per_gpu": N, "particles_total": N * world if sharded_mode else N, "T": T,
             "partition": "particle-sharded" if sharded_mode else ("single GPU" if world == 1 else "replicas"),
+            **({"hip_runtime": "system ROCm runtime preloaded (" + ":".join(SYSTEM_HIP) + "): the one bundled with PyTorch hangs in hipIpcOpenMemHandle above 2 GiB"}
+               if os.environ.get("PGAS_SYSTEM_HIP") else {}),
             **({"fallback_reason": "the particle-sharded sweep was requested but its setup failed; independent chains were measured instead: " + shard_fallback}
                if shard_fallback else {}),
             "parallelism": "1 GPU" if world == 1 and not sharded_mode else (

@@ -194,6 +194,11 @@ int pgas_shard_set_collective(pgas_ctx* ctx, pgas_allgather_fn fn, void* user);
 int pgas_shard_sweep(pgas_ctx* ctx, uint64_t seed, const double* ref_dev, double* traj_dev, int32_t propagate_chunk, void* stream);
 /* Measurement aid: issue the step's RCCL all-gather `reps` times on `stream` (between sweeps only). */
 int pgas_shard_probe_collective(pgas_ctx* ctx, int32_t reps, void* stream);
+/* Version of the HIP runtime this library is bound to in the running process (hipRuntimeGetVersion: 7.2.x = 702xxxxx), -1 on failure.
+ * Why a caller wants to know: the HIP 7.0 runtime bundled with PyTorch 2.10+rocm7.0 HANGS in hipIpcOpenMemHandle for allocations of
+ * 2 GiB and more (7.2 opens a 34 GB one in 0.3 ms); pgas_amd.sharded refuses to map such buffers through it. */
+int32_t pgas_hip_runtime_version(void);
+
 int pgas_ipc_export(pgas_ctx* ctx, int32_t which, void* handle64);
 int pgas_ipc_open(pgas_ctx* ctx, const void* handle64, void** ptr);
 
