@@ -321,7 +321,7 @@ class Engine:
         self._chk(self.lib.pgas_set_profiling(self._h, int(on)), "pgas_set_profiling")
 
     def profile(self):
-        """(k_resample launches, their total ms, k_propagate launches, their total ms) of the last sweep (synchronises)."""
+        """(k_step launches, their total ms, k_propagate launches, their total ms) of the last sweep (synchronises)."""
         n, ms, pn, pm = C.c_int64(), C.c_double(), C.c_int64(), C.c_double()
         self._chk(self.lib.pgas_get_profile(self._h, C.byref(n), C.byref(ms), C.byref(pn), C.byref(pm), self._stream()), "pgas_get_profile")
         return int(n.value), float(ms.value), int(pn.value), float(pm.value)

@@ -5,11 +5,9 @@
 //   k_init        x_0 ~ N(m0,P0)                                   src/PGAS.py:155-174,194
 //   k_front       per particle: basis, A phi, log-weights, propagate, per-segment softmax scans
 //                                                                   src/PGAS.py:45-77,90-118,130-134
-//   k_upper       cross-segment CDF (2 blocks: resampling CDF, ancestor CDF + ancestor search)
-//                                                                   src/PGAS.py:102,118,121-127
-//   k_back        systematic resampling search + weight update      src/Filtering.py:28-35, src/PGAS.py:137-147
-//   k_propagate   every particle through a range of time steps, state in registers (no synchronisation)
-//   k_resample    per step: resampling search of step t-1, weight update, softmax scans of step t
+//   k_propagate   every particle through a range of time steps (one by default), no synchronisation
+//   (pgas_resample.hip.h: k_groups, k_step, k_count, k_back, k_systematic -- the hierarchical CDF, the resampling search,
+//    the weight update and the ancestor of the conditioned particle, src/Filtering.py:28-35, src/PGAS.py:101-127,137-147)
 //   k_segscan     softmax scan of a weight vector (final index)     src/PGAS.py:224
 //   k_backtrace   ancestor chase                                    src/Filtering.py:40-55
 //   k_basis_eval  phi(x) in reference order (test hook)             src/BasisFunctions.py:77-80
@@ -33,7 +31,7 @@ static_assert(PG_BLK * PG_PPT == PGAS_SEG && PGAS_SEG == 1024, "one workgroup ow
 #define PG_MAX_NSEG 8192
 
 // Diagnostic build only (-DPG_STAMPS): per-workgroup wall-clock stamps (100 MHz s_memrealtime) at phase boundaries of
-// k_resample_fast, read back with pgas_debug_stamps.  No stamp executes in the product build.
+// k_step, read back with pgas_debug_stamps (tools/stamps_probe.py).  No stamp executes in the product build.
 #ifdef PG_STAMPS
 __device__ unsigned long long g_stamps[2048 * 16];
 #define PG_STAMP(id)                                                                                \
@@ -592,7 +590,7 @@ __global__ __launch_bounds__(PG_BLK) void k_init(DevModel md, uint64_t seed, con
 }
 
 // ------------------------------------------------------------------------------------------
-// segment softmax scan shared by k_front / k_resample / k_segscan.
+// segment softmax scan shared by k_front / k_step / k_segscan.
 // lw[r] is the log-weight of particle seg*SEG + r*BLK + tid (-inf when past N).  Writes the
 // quantised inclusive cumsum (index order) and the segment (max, total).
 // ------------------------------------------------------------------------------------------
@@ -878,8 +876,7 @@ __global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, TransParams tp, i
 //              inter-workgroup traffic.  Per particle-step it writes x_t (trace), la_t = log p(y_t|aux_t),
 //              h_t = log N(ref_t; aux_t, S) and ln_t = log p(y_t | x_t): everything the weight
 //              recursion needs later.
-// k_resample   one launch per time step: systematic-resampling search of step t-1 (needs k_upper(t-1)),
-//              logw_{t-1} = ln_{t-1} - la_{t-1}[a], then both softmax scans of step t.
+//              The weight recursion itself is k_step + k_groups (pgas_resample.hip.h).
 // ------------------------------------------------------------------------------------------
 // One group of P particles of this thread through one time step, start to finish (basis, transition mean, noise, the three
 // log-densities, new state): the FAST k_propagate walks its PG_PPT particles group by group so that only one group's
