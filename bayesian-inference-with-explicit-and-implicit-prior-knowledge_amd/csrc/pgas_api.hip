@@ -635,7 +635,7 @@ static int ensure_side_stream(pgas_ctx* c, int nchunk) {
     if (!c->sB) {
         int lo = 0, hi = 0;
         HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-        // measured (tools/overlap_exp.sh): the chain stream at LOW priority and one-step k_propagate launches overlap best
+        // round 1 measured the chain stream at LOW priority as best; with the round-2 kernels the priority makes no difference
         const char* pe = getenv("PGAS_CHAIN_PRIO");   // development knob: 1 = highest, 2 = default priority
         const int pr = pe && pe[0] == '1' ? hi : (pe && pe[0] == '2' ? 0 : lo);
         HIPCHK(c, hipStreamCreateWithPriority(&c->sB, hipStreamNonBlocking, pr));
@@ -791,7 +791,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
         if (c->logw_trace)
             HIPCHK(c, hipMemcpyAsync(c->logw_last, c->logw_trace + (size_t)(T - 1) * N, N * sizeof(double), hipMemcpyDeviceToDevice, st));
     } else {
-        // default chunk, measured (tools/overlap_exp.sh, tools/config_times.py): one step per k_propagate launch for the cheap 1-D / 2-D
+        // default chunk, measured (tools/ab_bench.py --chunk, tools/config_times.py): one step per k_propagate launch for the cheap 1-D / 2-D
         // bases, 16 for the 3-D bases whose k_propagate launches are ten times longer than a k_step launch
         const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 1 : T);
         c->last_chunk = chunk;
