@@ -212,16 +212,25 @@ def respawn_under_torchrun(args):
 SYSTEM_HIP = ("/opt/rocm/lib/libamdhip64.so", "/opt/rocm/lib/libhsa-runtime64.so")
 
 
+def system_hip_env(environ, mode, exists=os.path.exists):
+    """The environment a multi-rank run restarts itself with (system ROCm runtime preloaded), or None when no restart is due:
+    single-rank runs, a restart already done (PGAS_SYSTEM_HIP), PGAS_NO_PRELOAD set, or no system runtime on this machine."""
+    multi = int(environ.get("WORLD_SIZE", "1")) > 1 or ("WORLD_SIZE" in environ and mode == "sharded")
+    if not multi or environ.get("PGAS_SYSTEM_HIP") or environ.get("PGAS_NO_PRELOAD") or not all(exists(p) for p in SYSTEM_HIP):
+        return None
+    env = dict(environ)
+    env["PGAS_SYSTEM_HIP"] = "1"
+    env["LD_PRELOAD"] = ":".join(list(SYSTEM_HIP) + [p for p in env.get("LD_PRELOAD", "").split(":") if p and p not in SYSTEM_HIP])
+    return env
+
+
 def use_system_hip_runtime(args):
     """Multi-rank runs map their peers' trace buffers (tens of GB each) with hipIpcOpenMemHandle, and the HIP 7.0 runtime bundled with
     PyTorch 2.10+rocm7.0 hangs in that call for allocations >= 2 GiB (tools/ipc_probe.py).  ROCm 7.2's runtime does
     not: restart this rank with it preloaded -- an exec BEFORE anything has touched the GPU (torch is not even imported yet)."""
-    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1 or ("WORLD_SIZE" in os.environ and args.mode == "sharded")
-    if not multi or os.environ.get("PGAS_SYSTEM_HIP") or os.environ.get("PGAS_NO_PRELOAD") or not all(os.path.exists(p) for p in SYSTEM_HIP):
+    env = system_hip_env(os.environ, args.mode)
+    if env is None:
         return
-    env = dict(os.environ)
-    env["PGAS_SYSTEM_HIP"] = "1"
-    env["LD_PRELOAD"] = ":".join(list(SYSTEM_HIP) + [p for p in env.get("LD_PRELOAD", "").split(":") if p])
     sys.stderr.flush()
     os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env)
 
