@@ -85,6 +85,8 @@ def test_basis_init_step_bit_exact(name, N):
     ("smo", 1 << 17, {9: 1}),         # PGAS_OPT_TAIL_GROUPS: group scans handed to the last-arriving workgroup inside k_step
     ("smo", 70000, {9: 1}),           # ... ragged last group
     ("toy", 1500, {1: 1}),            # PGAS_OPT_PROPAGATE_CHUNK = 1: one k_propagate launch per step
+    # N <= 1024: one segment, one group
+    ("smo", 1024, {}), ("smo", 777, {}), ("toy", 300, {}), ("toy", 1, {}), ("emps", 500, {}), ("veh", 640, {}), ("veh27", 1000, {}), ("smo", 777, {7: 1}),
 ])
 def test_sweep_bit_exact(name, N, opts):
     pb, A, S, cm, csmc = _setup(name, N)
