@@ -464,6 +464,11 @@ def main():
                         oth["traffic_per_step"] = tj.get("k_propagate_hbm_bytes_per_step" if dom_is_step else "k_step_hbm_bytes_per_launch")
                         if "valu" in tj:
                             out["valu"] = tj["valu"]
+                            tot = sum((v.get("valu_instr_per_particle_step") or 0.0) for v in tj["valu"].values())
+                            # every VALU instruction of a wave64 occupies its SIMD for 4 cycles (16 lanes per clock); 1024 SIMDs at ~2.1 GHz under this load
+                            out["valu"]["summary"] = {"lane_instr_per_particle_step": tot, "issue_bound_us_per_step": tot * N / 64 * 4 / 1024 / 2.1e3,
+                                                      "measured_us_per_step": 1e6 * dt / args.steps / (T - 1),
+                                                      "note": "stored PMC counts (SQ_INSTS_VALU x 64 / N per kernel, profiles/traffic_r02.json), not taken in this run"}
                         break
             # SURVEY 8(d), secondary figure: algorithmic flops per particle-step = 2 M nx (Phi A^T) + M (D - 1) (products) against the
             # fp64 vector peak -- the bound that matters for the M = 729 configurations
@@ -484,8 +489,8 @@ def main():
                 "sweep_note": "sweep_* = 52 B x N x (T-1) / wall of the whole sweep per GPU: both kernels, launch gaps, final draw and back-trace included",
                 "hbm_copy_GBs": hbm_copy_rate(torch, eng.device),   # measured attainable rate of a 1 GiB device copy, outside the timed region
                 "second_kernel": oth,
-                "note": "the two kernels run concurrently on two streams; both are fp64-VALU-bound (DESIGN.md section 5, profiles/r02_pmc_sq_*.csv), "
-                        "so the HBM fraction understates how close they are to their own limit",
+                "note": "the two kernels run concurrently on two streams; k_propagate is fp64-VALU-bound (82 % VALU-busy alone), k_step is a chain of dependent "
+                        "global round trips (70 % of its wave cycles are waits): DESIGN.md section 5, profiles/r02_pmc_sq_*.txt -- the HBM fraction says little about either",
             }
         if args.cpu_steps > 0 and world == 1:
             Ah, Sh = A.cpu().numpy(), S.cpu().numpy()
