@@ -85,6 +85,8 @@ def test_basis_init_step_bit_exact(name, N):
     ("smo", 1 << 17, {9: 1}),         # PGAS_OPT_TAIL_GROUPS: group scans handed to the last-arriving workgroup inside k_step
     ("smo", 70000, {9: 1}),           # ... ragged last group
     ("toy", 1500, {1: 1}),            # PGAS_OPT_PROPAGATE_CHUNK = 1: one k_propagate launch per step
+    ("smo", 5000, {8: 3, 11: 2}),     # PGAS_OPT_EVENT_STRIDE = 3, PGAS_OPT_MAX_LEAD = 2: k_propagate at most two event groups ahead of the chain
+    ("smo", 5000, {3: 0}),            # PGAS_OPT_OVERLAP = 0: both pipelines on the caller's stream
     # N <= 1024: one segment, one group
     ("smo", 1024, {}), ("smo", 777, {}), ("toy", 300, {}), ("toy", 1, {}), ("emps", 500, {}), ("veh", 640, {}), ("veh27", 1000, {}), ("smo", 777, {7: 1}),
 ])
