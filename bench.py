@@ -286,6 +286,11 @@ def main():
     # a launcher (torch.distributed.run) with ONE rank and an explicit --mode sharded runs the sharded code path with world = 1:
     # the same kernels and one-rank RCCL collectives, no wire time -- the figure to hold against the unsharded sweep
     use_dist = world > 1 or ("WORLD_SIZE" in os.environ and args.mode == "sharded")
+    if use_dist and not rehearse:
+        # a multi-rank run that stops making progress (a collective nobody answers, a driver call that never returns) should end with a
+        # stack trace and a non-zero exit, not sit there until someone's timeout: setup + 6 sweeps take well under a minute
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("PGAS_BENCH_WATCHDOG_S", "900")), exit=True, file=sys.stderr)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearse:
@@ -501,6 +506,9 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+        if not rehearse:
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
 
 
 if __name__ == "__main__":
