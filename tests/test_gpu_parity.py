@@ -315,6 +315,67 @@ def test_eight_shards_five_million_particles():
         _eq(LW, lwo[r * Nl:(r + 1) * Nl], f"log_weights shard {r}")
 
 
+def test_config3_geometry_eight_million_particles():
+    """BASELINE configs[3]'s exact geometry -- N = 2^23 = 8192 segments = 128 groups = two FULL top-level blocks, which is also the
+    engine's capacity (PG_MAX_NSEG, PG_MAX_GRP = 128) -- executed both ways against ONE run of the canonical oracle, bit for bit:
+    (a) 8 shards x 1024 segments (the partition of the 8-GPU run, emulated on one device: every rank's window is 1/8 of the CDF,
+        most ancestors are remote), traces and trajectory on every rank;
+    (b) one unsharded context at the pgas_create limit itself (k_step grid of 8193 workgroups), sweep and step API."""
+    from pgas_amd import sharded
+
+    world, Nl = 8, 1024 * 1024
+    N = world * Nl
+    T = 3
+    pb = experiments.smo_pgas(T=T)
+    A, S = experiments.initial_params(pb)
+    cm = canon_model(pb, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    L0 = np.linalg.cholesky(pb.init_state_cov)
+    trajo, Xo, ANCo, lwo = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, L0)
+    # (a) sharded 8 x 2^20
+    grp = sharded.make_local_group(world, N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+    trajs = sharded.sharded_sweep(grp, SEED, pb.X_true, A, S)
+    for r, (s, tr) in enumerate(zip(grp.shards, trajs)):
+        _eq(tr, trajo.reshape(tr.shape), f"trajectory on rank {r}")
+        X, ANC, LW, _ = s.eng.traces()
+        _eq(X, Xo[:, r * Nl:(r + 1) * Nl], f"state_trace shard {r}")
+        _eq(ANC[: T - 1], ANCo[:, r * Nl:(r + 1) * Nl], f"ancestor_trace shard {r}")
+        _eq(LW, lwo[r * Nl:(r + 1) * Nl], f"log_weights shard {r}")
+    for s in grp.shards:
+        s.eng.close()
+    del grp, trajs
+    torch.cuda.empty_cache()
+    # (b) unsharded, N = 2^23 on one device
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn)
+    traj = csmc(SEED, pb.X_true, A, S)
+    X, ANC, LW, _ = csmc.engine.traces()
+    _eq(X, Xo, "state_trace at N=2^23")
+    _eq(ANC[: T - 1], ANCo, "ancestor_trace at N=2^23")
+    _eq(LW, lwo, "log_weights at N=2^23")
+    _eq(traj, trajo.reshape(traj.shape), "trajectory at N=2^23")
+    # step API at the same size: step 2 from the oracle's own step-1 state (teacher-forced)
+    lw1, x1, _ = cm.step(1, SEED, Xo[0], None, A, LS, LSinv, cS, pb.X_true[1])
+    lw2, x2, a2 = cm.step(2, SEED, x1, lw1, A, LS, LSinv, cS, pb.X_true[2])
+    lwg, xg, ag = csmc.step(SEED, 2, torch.as_tensor(lw1), torch.as_tensor(x1), A, S, pb.X_true[2])
+    _eq(xg, x2, "step API new_state at N=2^23")
+    _eq(ag, a2, "step API a_indices at N=2^23")
+    _eq(lwg, lw2, "step API new_log_weights at N=2^23")
+
+
+def test_capacity_limits_are_clean_errors():
+    """One particle beyond the capacity (8193 segments) is refused by pgas_create with a message, and so is a shard layout whose global
+    segment count exceeds it -- never a silent wrap of the 128-group top level."""
+    from pgas_amd import sharded
+    from pgas_amd._lib import PgasError
+
+    pb = experiments.smo_pgas(T=3)
+    with pytest.raises(PgasError, match="exceeds"):
+        pgas_amd.condSequentialMonteCarlo((1 << 23) + 1, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+    with pytest.raises(PgasError, match="exceed"):
+        sharded.make_local_group(8, 8 * 1025 * 1024, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+
+
 def test_filtering_free_functions():
     """src/Filtering.py mirror: systematic_SISR KATs and reconstruct_trajectory on a hand-built ancestry."""
     from oracle import pgas_numpy as o

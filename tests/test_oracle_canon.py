@@ -157,11 +157,13 @@ def test_corrected_mode_matches_numpy(name, N):
     assert np.array_equal(ad, ak) and not np.array_equal(xd, xk)
 
 
-@pytest.mark.parametrize("nseg,spread", [(70, 0.0), (200, 40.0), (4200, 3.0), (4200, 300.0)])
+@pytest.mark.parametrize("nseg,spread", [(70, 0.0), (200, 40.0), (4200, 3.0), (4200, 300.0), (8192, 3.0), (8192, 300.0)])
 def test_hierarchical_cdf_against_exact_arithmetic(nseg, spread):
     """The three-level CDF of DESIGN.md 4.4 (segment -> group of 64 -> blocks of 64 groups) on synthetic log-weights with very different
     scales from segment to segment (groups and blocks get different power-of-two references): resampled indices must equal
-    searchsorted on an exactly summed softmax away from ties, for 1, 2 and 66 groups (the last one exercises the second top-level block)."""
+    searchsorted on an exactly summed softmax away from ties, for 1, 2, 66 and 128 groups (66 exercises the second top-level block;
+    8192 segments = 128 groups = two FULL top-level blocks is the engine's capacity PG_MAX_NSEG and the geometry of BASELINE configs[3],
+    N = 2^23 over 8 GPUs)."""
     rng = np.random.default_rng(nseg)
     N = nseg * 1024 - 300
     base = np.repeat(rng.uniform(-spread, 0.0, nseg), 1024)[:N]
