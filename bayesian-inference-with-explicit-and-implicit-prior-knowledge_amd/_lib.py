@@ -37,7 +37,8 @@ EXPORTS = [
     "pgas_aux_states", "pgas_init_state", "pgas_step", "pgas_sweep", "pgas_get_traces", "pgas_last_final_index",
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
-    "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_set_peer", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
+    "pgas_trace_layout", "pgas_trace_row",
+    "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_layout", "pgas_shard_block", "pgas_shard_set_peer_block", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
     "pgas_hip_runtime_version", "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
     "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_chi2", "pgas_m_set_time_source", "pgas_m_rng_uniform_dev", "pgas_systematic_resample_dev", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
 ]
@@ -95,8 +96,16 @@ def load():
     L.pgas_shard_setup.argtypes = [vp, i32, i32]
     L.pgas_shard_buffers.restype = C.c_int
     L.pgas_shard_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(i64)]
-    L.pgas_shard_set_peer.restype = C.c_int
-    L.pgas_shard_set_peer.argtypes = [vp, i32, C.POINTER(vp)]
+    L.pgas_shard_layout.restype = C.c_int
+    L.pgas_shard_layout.argtypes = [vp, i32, C.POINTER(i64)]
+    L.pgas_shard_block.restype = C.c_int
+    L.pgas_shard_block.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i64)]
+    L.pgas_shard_set_peer_block.restype = C.c_int
+    L.pgas_shard_set_peer_block.argtypes = [vp, i32, i32, i32, vp]
+    L.pgas_trace_layout.restype = C.c_int
+    L.pgas_trace_layout.argtypes = [vp, i32, C.POINTER(i64)]
+    L.pgas_trace_row.restype = C.c_int
+    L.pgas_trace_row.argtypes = [vp, i32, i32, C.POINTER(vp)]
     L.pgas_shard_run.restype = C.c_int
     L.pgas_shard_run.argtypes = [vp, i32, i32, i32, u64, vp, vp, vp]
     L.pgas_shard_unique_id.restype = C.c_int
@@ -114,7 +123,7 @@ def load():
     L.pgas_get_launch_info.restype = C.c_int
     L.pgas_get_launch_info.argtypes = [vp, C.POINTER(i32)]
     L.pgas_ipc_export.restype = C.c_int
-    L.pgas_ipc_export.argtypes = [vp, i32, C.c_char_p]
+    L.pgas_ipc_export.argtypes = [vp, i32, i32, C.c_char_p]
     L.pgas_hip_runtime_version.restype = C.c_int32
     L.pgas_hip_runtime_version.argtypes = []
     L.pgas_ipc_open.restype = C.c_int
@@ -301,12 +310,40 @@ class Engine:
         self._ref_keepalive = ref
         return traj
 
-    def traces(self):
-        """(state_trace (T,N,nx), ancestor_trace (T-1,N) int32, logw_last (N), logw_trace (T,N)|None) views."""
+    TRACE_X, TRACE_LA, TRACE_H, TRACE_LN, TRACE_ANC = range(5)
+
+    def trace_layout(self, kind):
+        """(rows, rows per block, blocks, bytes per row) of trace `kind` (pgas_trace_layout)."""
+        v = (C.c_int64 * 4)()
+        self._chk(self.lib.pgas_trace_layout(self._h, int(kind), v), "pgas_trace_layout")
+        return tuple(int(x) for x in v)
+
+    def trace_row(self, kind, t):
+        """Device pointer of time row t of trace `kind` (pgas_trace_row)."""
+        p = C.c_void_p()
+        self._chk(self.lib.pgas_trace_row(self._h, int(kind), int(t), C.byref(p)), "pgas_trace_row")
+        return int(p.value)
+
+    def traces_blocks(self, kind, row_shape, dtype):
+        """The row blocks of trace `kind` as torch views of library-owned memory, in time order."""
+        rows, rpb, nblk, _ = self.trace_layout(kind)
+        return [self.dev_tensor(self.trace_row(kind, b * rpb), (min(rpb, rows - b * rpb),) + tuple(row_shape), dtype) for b in range(nblk)]
+
+    def traces(self, copy_blocks=True):
+        """(state_trace (T,N,nx), ancestor_trace (T-1,N) int32, logw_last (N), logw_trace (T,N)|None).  Views of library-owned memory on
+        an unsharded context; a context that keeps its traces in row blocks (shards, PGAS_OPT_TRACE_BLOCK_BYTES) returns concatenated
+        COPIES of x / ancestors (None with copy_blocks=False: use traces_blocks for views of the blocks)."""
         px, pa, pl, pt = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
-        self._chk(self.lib.pgas_get_traces(self._h, C.byref(px), C.byref(pa), C.byref(pl), C.byref(pt)), "pgas_get_traces")
-        X = torch.as_tensor(_DevView(px.value, (self.T, self.N, self.nx), "<f8", self), device=self.device)
-        A = torch.as_tensor(_DevView(pa.value, (max(self.T - 1, 1), self.N), "<i4", self), device=self.device)
+        if self.trace_layout(self.TRACE_X)[2] == 1 and self.trace_layout(self.TRACE_ANC)[2] == 1:
+            px.value, pa.value = self.trace_row(self.TRACE_X, 0), self.trace_row(self.TRACE_ANC, 0)
+            X = torch.as_tensor(_DevView(px.value, (self.T, self.N, self.nx), "<f8", self), device=self.device)
+            A = torch.as_tensor(_DevView(pa.value, (max(self.T - 1, 1), self.N), "<i4", self), device=self.device)
+        elif copy_blocks:
+            X = torch.cat(self.traces_blocks(self.TRACE_X, (self.N, self.nx), torch.float64))
+            A = torch.cat(self.traces_blocks(self.TRACE_ANC, (self.N,), torch.int32))
+        else:
+            X = A = None
+        self._chk(self.lib.pgas_get_traces(self._h, None, None, C.byref(pl), C.byref(pt)), "pgas_get_traces")
         Lw = torch.as_tensor(_DevView(pl.value, (self.N,), "<f8", self), device=self.device)
         Lt = torch.as_tensor(_DevView(pt.value, (self.T, self.N), "<f8", self), device=self.device) if pt.value else None
         return X, A, Lw, Lt
@@ -383,9 +420,20 @@ class Engine:
         self._chk(self.lib.pgas_shard_buffers(self._h, out, sz), "pgas_shard_buffers")
         return [int(p or 0) for p in out], tuple(int(v) for v in sz)
 
-    def shard_set_peer(self, peer, ptrs7):
-        arr = (C.c_void_p * 7)(*[C.c_void_p(p) for p in ptrs7])
-        self._chk(self.lib.pgas_shard_set_peer(self._h, peer, arr), "pgas_shard_set_peer")
+    def shard_layout(self, which):
+        """(blocks, rows per block) of peer-visible buffer `which` (0, 1: segment cumsums; 2..6: la, h, ln, x, anc)."""
+        v = (C.c_int64 * 2)()
+        self._chk(self.lib.pgas_shard_layout(self._h, int(which), v), "pgas_shard_layout")
+        return int(v[0]), int(v[1])
+
+    def shard_block(self, which, blk):
+        """(device pointer, bytes) of block `blk` of this rank's buffer `which`."""
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self.lib.pgas_shard_block(self._h, int(which), int(blk), C.byref(p), C.byref(n)), "pgas_shard_block")
+        return int(p.value), int(n.value)
+
+    def shard_set_peer_block(self, peer, which, blk, ptr):
+        self._chk(self.lib.pgas_shard_set_peer_block(self._h, int(peer), int(which), int(blk), C.c_void_p(int(ptr))), "pgas_shard_set_peer_block")
 
     def shard_run(self, phase, t=0, t_aux=0, seed=0, ref=None, traj=None):
         self._chk(
@@ -440,7 +488,7 @@ class Engine:
         """dict(chunk, local_groups, JP, P) of the last sweep (pgas_get_launch_info)."""
         v = (C.c_int32 * 4)()
         self._chk(self.lib.pgas_get_launch_info(self._h, v), "pgas_get_launch_info")
-        return dict(chunk=int(v[0]), local_groups=int(v[1]) == 1, groups={0: "k_groups", 1: "local", 2: "tail"}[int(v[1])], JP=int(v[2]), P=int(v[3]))
+        return dict(chunk=int(v[0]), local_groups=int(v[1]) == 1, groups={0: "k_groups", 1: "local", 2: "tail", 3: "abs"}[int(v[1])], JP=int(v[2]), P=int(v[3]))
 
     def shard_sweep(self, seed, ref, traj, propagate_chunk=0):
         self._ag_error = None
@@ -449,9 +497,9 @@ class Engine:
             raise PgasError(f"pgas_shard_sweep: the all-gather callback raised:\n{self._ag_error}")
         self._chk(rc, "pgas_shard_sweep")
 
-    def ipc_export(self, which):
+    def ipc_export(self, which, blk=0):
         buf = C.create_string_buffer(64)
-        self._chk(self.lib.pgas_ipc_export(self._h, which, buf), "pgas_ipc_export")
+        self._chk(self.lib.pgas_ipc_export(self._h, int(which), int(blk), buf), "pgas_ipc_export")
         return bytes(buf.raw)
 
     def ipc_open(self, handle):

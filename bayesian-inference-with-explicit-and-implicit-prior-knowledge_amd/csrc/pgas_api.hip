@@ -5,6 +5,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -90,7 +91,7 @@ struct DeviceGuard {
 
 typedef void (*front_fn)(DevModel, TransParams, int, uint64_t, const double*, const double*, const double*, int, double*, ScanBufs);
 typedef void (*backc_fn)(DevModel, TransParams, int, uint64_t, double, const double*, const double*, ScanBufs, Peers, int32_t*, double*, double*);
-typedef void (*prop_fn)(DevModel, TransParams, uint64_t, int, int, double*, const double*, double*, double*, double*);
+typedef void (*prop_fn)(DevModel, TransParams, uint64_t, int, int, const double*, double*, const double*, double*, double*, double*);
 typedef void (*aux_fn)(DevModel, TransParams, int, const double*, double*);
 typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, Peers, int32_t*, double*);
 typedef void (*init_fn)(DevModel, uint64_t, const double*, const double*, double*);
@@ -139,6 +140,24 @@ bool pick_variant(int nx, int D, int jin_needed, bool fast, int J0, Variant* v, 
     return true;
 }
 
+// One trace buffer (T or T-1 rows of equal size) as row blocks: one allocation in the contiguous layout (unsharded contexts: the
+// caller gets plain (T, N, ...) arrays from pgas_get_traces), power-of-two runs of rows of at most `block_bytes` each otherwise
+// (sharded contexts: every block stays below the 2 GiB above which hipIpcOpenMemHandle of PyTorch's bundled runtime hangs).
+struct RowStore {
+    std::vector<void*> own;     // allocations
+    std::vector<char*> blk;     // base of block b = rows [b << shift, (b + 1) << shift)
+    size_t row_bytes = 0;
+    int rows = 0, shift = 30, nblk = 0;
+    bool contiguous = true;
+    char* row(int t) const { return blk[(size_t)t >> shift] + (size_t)(t & ((1 << shift) - 1)) * row_bytes; }
+    int rows_in_block(int b) const { const int r0 = b << shift, r1 = r0 + (1 << shift); return (r1 < rows ? r1 : rows) - r0; }
+    void release() {
+        for (void* p : own) hipFree(p);
+        own.clear(); blk.clear(); nblk = 0; rows = 0;
+    }
+};
+#define PG_TRACE_BLOCK_BYTES ((size_t)1 << 30)
+
 }  // namespace
 
 struct pgas_ctx {
@@ -171,14 +190,17 @@ struct pgas_ctx {
     TransParams tp{};
     bool have_params = false;
     ScanBufs sb[2]{};
-    // traces
-    double* x_trace = nullptr;
-    int32_t* anc_trace = nullptr;
+    // traces: rs[PG_RB_X] (T rows of (N, nx)), rs[PG_RB_ANC] (T-1 rows of N int32), and the hand-off rows k_propagate writes for the
+    // weight recursion: rs[PG_RB_LA] log p(y_t | aux_t), rs[PG_RB_H] log N(ref_t; aux_t, S), rs[PG_RB_LN] log p(y_t | x_t), T rows of nseg*SEG each
+    RowStore rs[PG_RB_NKIND];
+    bool have_traces = false;
+    size_t trace_block_bytes = 0;   // PGAS_OPT_TRACE_BLOCK_BYTES: 0 = contiguous (unsharded) / PG_TRACE_BLOCK_BYTES (sharded)
+    std::vector<const char*> peer_blk[PG_MAX_RANKS][PG_RB_NKIND];   // every rank's block bases as mapped into this process (own rank: rs[].blk)
+    const void** d_bt = nullptr;    // device copy of the x / ancestor block table for k_backtrace
+    size_t d_bt_entries = 0;
+    bool bt_dirty = true;
     double* logw_last = nullptr;
     double* logw_trace = nullptr;
-    double* la_buf = nullptr;   // (T, nseg*SEG) log p(y_t | aux_t)      written by k_propagate
-    double* h_buf = nullptr;    // (T, nseg*SEG) log N(ref_t; aux_t, S)
-    double* ln_buf = nullptr;   // (T, nseg*SEG) log p(y_t | x_t)
     double* laux_own[2] = {nullptr, nullptr};  // laux of the two step-API scan buffers
     int prop_chunk = 0;         // time steps per k_propagate launch (0 = whole sweep)
     Peers peers{};              // world == 1 unless pgas_shard_setup was called
@@ -193,6 +215,7 @@ struct pgas_ctx {
     int last_chunk = 0;         // time steps per k_propagate launch of the last sweep
     int var_P = 0;              // particles per basis pass of the k_propagate variant
     unsigned launch_tag = 0;    // unique id per k_step launch (hand-off word tag)
+    int no_abs = 1;             // development knob (PGAS_ABS=1 in the environment at pgas_create selects the absolute-record path)
     int force_slow = 0;         // 1: never let k_step scan the groups itself (test hook for the k_groups path taken when N > 2^20 per device)
     int tail_groups = 0;        // PGAS_OPT_TAIL_GROUPS: 1 = group scans in k_step's tail instead of k_groups launches (single device; slower, kept as an experiment)
     int ev_stride = 8;          // PGAS_OPT_EVENT_STRIDE: k_propagate launches per event that gates the weight recursion
@@ -255,6 +278,9 @@ static int alloc_scanbufs(pgas_ctx* c, ScanBufs* sb) {
     HIPCHK(c, hipMalloc(&sb->tab_e, 2 * nsegp * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->tab_sc, 2 * nsegp * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->tab_m, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->abs_cm, 2 * nsegp * sizeof(double)));
+    HIPCHK(c, hipMalloc(&sb->abs_dexp, 2 * nsegp * sizeof(int32_t)));
+    HIPCHK(c, hipMalloc(&sb->abs_grp, 2 * 4 * PG_ABS_WAVES * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->grp_K, 2 * PG_MAX_GRP * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->grp_T, 2 * PG_MAX_GRP * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->grp_cnt, PG_MAX_GRP * sizeof(unsigned)));
@@ -270,6 +296,7 @@ static int alloc_scanbufs(pgas_ctx* c, ScanBufs* sb) {
 }
 static void free_scanbufs(ScanBufs* sb) {
     hipFree(sb->laux); hipFree(sb->c1); hipFree(sb->c2); hipFree(sb->segk_w); hipFree(sb->segs_w);  // segk/segs alias these or the gathered arrays
+    hipFree(sb->abs_cm); hipFree(sb->abs_dexp); hipFree(sb->abs_grp);
     hipFree(sb->tab_e); hipFree(sb->tab_sc); hipFree(sb->tab_m); hipFree(sb->grp_K); hipFree(sb->grp_T); hipFree(sb->grp_cnt); hipFree(sb->hdr);
     *sb = ScanBufs{};
 }
@@ -331,6 +358,7 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
     c->init = d->nx == 1 ? k_init<1> : k_init<2>;
     c->basis = d->nx == 1 ? k_basis_eval<1> : k_basis_eval<2>;
     c->keep_logw = d->keep_logw_trace;
+    { const char* e = getenv("PGAS_ABS"); c->no_abs = !(e && e[0] == '1'); }   // absolute-record path: opt-in while it measures slower
 
     c->device = d->device;
     // grid positions of the basis functions, innermost dimension padded to JP
@@ -406,9 +434,10 @@ void pgas_destroy(pgas_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_qdesc); hipFree(c->d_m0L0); hipFree(c->d_ref);
-    hipFree(c->d_G); hipFree(c->x_trace); hipFree(c->anc_trace); hipFree(c->logw_last); hipFree(c->logw_trace);
+    hipFree(c->d_G); hipFree(c->logw_last); hipFree(c->logw_trace); hipFree(c->d_bt);
+    for (RowStore& r : c->rs) r.release();
     hipFree(c->segk_g[0]); hipFree(c->segk_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
-    hipFree(c->d_phi); hipFree(c->d_syrk_ws); hipFree(c->la_buf); hipFree(c->h_buf); hipFree(c->ln_buf); hipFree(c->aux_buf); hipFree(c->d_fail); hipFree(c->ws_partial); hipFree(c->d_sync);
+    hipFree(c->d_phi); hipFree(c->d_syrk_ws); hipFree(c->aux_buf); hipFree(c->d_fail); hipFree(c->ws_partial); hipFree(c->d_sync);
     if (c->comm && rccl().destroy) rccl().destroy(c->comm);
     for (hipEvent_t e : c->ev) hipEventDestroy(e);
     for (hipEvent_t e : c->evp) hipEventDestroy(e);
@@ -488,12 +517,58 @@ static Peers peers_for(const pgas_ctx* c, int parity) {
 // this context's own buffers as "rank" c->rank of the peer table (single device: rank 0)
 static void install_own_peers(pgas_ctx* c) {
     const int r = c->rank;
-    c->peers.la[r] = c->la_buf; c->peers.h[r] = c->h_buf; c->peers.ln[r] = c->ln_buf;
-    c->peers.x[r] = c->x_trace; c->peers.anc[r] = c->anc_trace;
+    for (int k = 0; k < PG_RB_NKIND; ++k) c->peer_blk[r][k].assign(c->rs[k].blk.begin(), c->rs[k].blk.end());
+    c->bt_dirty = true;
     for (int i = 0; i < 2; ++i) {
         c->peer_c1[i][r] = c->sb[i].c1;
         c->peer_c2[i][r] = c->sb[i].c2;
     }
+}
+
+// row t of trace `kind` on rank r, as addressable from this device (same block layout on every rank: equal N_local and T)
+static const char* peer_row(const pgas_ctx* c, int r, int kind, int t) {
+    const RowStore& s = c->rs[kind];
+    return c->peer_blk[r][kind][(size_t)t >> s.shift] + (size_t)(t & ((1 << s.shift) - 1)) * s.row_bytes;
+}
+
+// device copy of the (rank, {x, anc}, block) table the ancestor chase walks
+static int upload_bt_table(pgas_ctx* c, hipStream_t st, BtTab* out) {
+    const int nb = std::max(c->rs[PG_RB_X].nblk, c->rs[PG_RB_ANC].nblk);
+    const size_t entries = (size_t)c->world * 2 * nb;
+    if (c->bt_dirty || c->d_bt_entries != entries) {
+        std::vector<const void*> h(entries, nullptr);
+        for (int r = 0; r < c->world; ++r) {
+            const auto& bx = c->peer_blk[r][PG_RB_X];
+            const auto& ba = c->peer_blk[r][PG_RB_ANC];
+            for (size_t b = 0; b < bx.size(); ++b) h[((size_t)r * 2) * nb + b] = bx[b];
+            for (size_t b = 0; b < ba.size(); ++b) h[((size_t)r * 2 + 1) * nb + b] = ba[b];
+        }
+        HIPCHK(c, hipStreamSynchronize(st));   // an earlier chase may still be reading the old table
+        if (c->d_bt_entries != entries) {
+            hipFree(c->d_bt);
+            c->d_bt = nullptr; c->d_bt_entries = 0;
+            HIPCHK(c, hipMalloc(&c->d_bt, entries * sizeof(void*)));
+            c->d_bt_entries = entries;
+        }
+        HIPCHK(c, hipMemcpy(c->d_bt, h.data(), entries * sizeof(void*), hipMemcpyHostToDevice));
+        c->bt_dirty = false;
+    }
+    out->blk = c->d_bt;
+    out->nblk_max = nb;
+    out->shift_x = c->rs[PG_RB_X].shift;
+    out->shift_anc = c->rs[PG_RB_ANC].shift;
+    out->entries = (int32_t)entries;
+    return PGAS_OK;
+}
+
+static int launch_backtrace(pgas_ctx* c, const UpperHdr* hdr, double* traj_dev, hipStream_t st) {
+    BtTab tab;
+    int rc = upload_bt_table(c, st, &tab);
+    if (rc) return rc;
+    const size_t lds = tab.entries <= 2048 ? (size_t)tab.entries * sizeof(void*) : 0;
+    hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), lds, st, c->md.N, c->md.T, c->md.nx, tab, c->world, hdr, traj_dev);
+    KCHK(c, "k_backtrace");
+    return PGAS_OK;
 }
 
 // group records of `ncdf` CDFs from the (gathered) segment partials of sb
@@ -516,6 +591,13 @@ static int launch_count(pgas_ctx* c, const ScanBufs& sb, int parity, int what, d
 // issue than the extra tiny launch costs latency).  PGAS_OPT_LOCAL_GROUPS selects it.
 static bool sweep_is_local(const pgas_ctx* c) { return c->local_groups && c->world == 1 && !c->sharded && c->md.nseg_g <= PG_LOCAL_NSEG && !c->force_slow; }
 
+// Default on one device with <= 1024 segments: k_groups_abs between the steps (absolute records, one workgroup) and k_step<PG_WM_ABS>,
+// whose workgroups fill their window with one round of loads.  PGAS_OPT_FORCE_SLOW_RESAMPLE keeps the general path (k_groups + a top
+// scan per workgroup: what larger devices and sharded sweeps run) so that the tests can exercise it at small sizes.
+static bool sweep_is_abs(const pgas_ctx* c) {
+    return !c->sharded && c->world == 1 && c->md.nseg_g <= PG_WIN_SEG && !c->force_slow && !c->local_groups && !c->tail_groups && !c->no_abs;
+}
+
 // PGAS_OPT_TAIL_GROUPS (single device only; sharded sweeps need the all-gather first): the group scans ride in k_step's tail, done by
 // the workgroup that completes a group, instead of a k_groups launch between the steps.  Correct and bit-identical, but measured
 // SLOWER (88.5 against 84.9 ms per sweep at N = 2^20: the write-through stores, the drain and the returning atomic at the end of
@@ -526,28 +608,36 @@ static bool sweep_tail_groups(const pgas_ctx* c) { return !c->sharded && c->worl
 static int launch_step(pgas_ctx* c, int t, uint64_t seed, bool local, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const DevModel& md = c->md;
     const int N = md.N, T = md.T;
-    const size_t np = (size_t)md.nseg * PGAS_SEG;
     StepArgs ar;
     ar.t = t;
     ar.mode = (t < T ? PG_RS_SCAN : 0) | (t > 1 ? PG_RS_SEARCH : 0);
     ar.tag = ++c->launch_tag;
     ar.u1_prev = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)) : 0.0;
     ar.u2_prev = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)(t - 1)) : 0.0;
-    ar.la_t = t < T ? c->la_buf + (size_t)t * np : (const double*)nullptr;
-    ar.h_t = t < T ? c->h_buf + (size_t)t * np : (const double*)nullptr;
-    ar.ln_prev = c->ln_buf + (size_t)(t - 1) * np;
-    ar.row_prev = (int64_t)((size_t)(t - 1) * np);
-    ar.anc_in.row_s = (int64_t)((size_t)(t - 1) * np);
-    ar.anc_in.row_p = t > 2 ? (int64_t)((size_t)(t - 2) * np) : -1;
-    ar.anc_in.anc_row_p = t > 2 ? (int64_t)((size_t)(t - 3) * N) : 0;
-    ar.anc_out = t > 1 ? c->anc_trace + (size_t)(t - 2) * N : (int32_t*)nullptr;
+    ar.la_t = t < T ? (const double*)c->rs[PG_RB_LA].row(t) : (const double*)nullptr;
+    ar.h_t = t < T ? (const double*)c->rs[PG_RB_H].row(t) : (const double*)nullptr;
+    ar.ln_prev = (const double*)c->rs[PG_RB_LN].row(t - 1);
+    ar.anc_in = AncIn{};
+    ar.anc_in.has_prev = t > 2 ? 1 : 0;
+    if (t > 1)
+        for (int r = 0; r < c->world; ++r) {   // rows of step s = t-1 (and s-1) on every rank
+            ar.anc_in.la_s[r] = (const double*)peer_row(c, r, PG_RB_LA, t - 1);
+            ar.anc_in.h_s[r] = (const double*)peer_row(c, r, PG_RB_H, t - 1);
+            if (t > 2) {
+                ar.anc_in.ln_p[r] = (const double*)peer_row(c, r, PG_RB_LN, t - 2);
+                ar.anc_in.la_p[r] = (const double*)peer_row(c, r, PG_RB_LA, t - 2);
+                ar.anc_in.anc_p[r] = (const int32_t*)peer_row(c, r, PG_RB_ANC, t - 3);
+            }
+        }
+    ar.anc_out = t > 1 ? (int32_t*)c->rs[PG_RB_ANC].row(t - 2) : (int32_t*)nullptr;
     ar.logw_out = t == T ? c->logw_last : ((c->logw_trace && t > 1) ? c->logw_trace + (size_t)(t - 1) * N : (double*)nullptr);
     const ScanBufs& sp = c->sb[(t - 1) & 1];
     const ScanBufs& sn = c->sb[t & 1];
     const Peers pr = peers_for(c, (t - 1) & 1);
-    if (local) hipExtLaunchKernelGGL((k_step<true, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
-    else if (sweep_tail_groups(c)) hipExtLaunchKernelGGL((k_step<false, true>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
-    else hipExtLaunchKernelGGL((k_step<false, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    if (local) hipExtLaunchKernelGGL((k_step<PG_WM_LOCAL, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    else if (sweep_tail_groups(c)) hipExtLaunchKernelGGL((k_step<PG_WM_GROUPS, true>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    else if (sweep_is_abs(c)) hipExtLaunchKernelGGL((k_step<PG_WM_ABS, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    else hipExtLaunchKernelGGL((k_step<PG_WM_GROUPS, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
     KCHK(c, "k_step");
     return PGAS_OK;
 }
@@ -584,21 +674,50 @@ int pgas_step(pgas_ctx* c, int32_t t, uint64_t seed, const double* logw_dev, con
     return PGAS_OK;
 }
 
-static int ensure_traces(pgas_ctx* c) {
-    if (c->x_trace) return PGAS_OK;
+// rows x row_bytes as one allocation (block_bytes == 0) or as power-of-two runs of rows of at most block_bytes each
+static int alloc_rows(pgas_ctx* c, RowStore* s, int rows, size_t row_bytes, size_t block_bytes) {
+    s->release();
+    s->rows = rows; s->row_bytes = row_bytes;
+    if (block_bytes == 0) {
+        s->contiguous = true; s->shift = 30; s->nblk = 1;
+        void* p = nullptr;
+        HIPCHK(c, hipMalloc(&p, (size_t)rows * row_bytes));
+        s->own.push_back(p);
+        s->blk.push_back((char*)p);
+        return PGAS_OK;
+    }
+    if (row_bytes > block_bytes) FAIL(c, PGAS_E_ARG, "trace rows of %zu bytes do not fit blocks of %zu bytes", row_bytes, block_bytes);
+    int shift = 0;
+    while (shift < 30 && ((size_t)2 << shift) * row_bytes <= block_bytes) ++shift;
+    s->contiguous = false; s->shift = shift; s->nblk = (rows + (1 << shift) - 1) >> shift;
+    for (int b = 0; b < s->nblk; ++b) {
+        void* p = nullptr;
+        HIPCHK(c, hipMalloc(&p, (size_t)s->rows_in_block(b) * row_bytes));
+        s->own.push_back(p);
+        s->blk.push_back((char*)p);
+    }
+    return PGAS_OK;
+}
+
+static int ensure_traces(pgas_ctx* c, bool blocked) {
+    if (c->have_traces) return PGAS_OK;
     const DevModel& md = c->md;
-    const size_t row = (size_t)md.N * md.nx;
-    HIPCHK(c, hipMalloc(&c->x_trace, (size_t)md.T * row * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->anc_trace, (size_t)(md.T > 1 ? md.T - 1 : 1) * md.N * sizeof(int32_t)));
-    HIPCHK(c, hipMalloc(&c->logw_last, (size_t)md.N * sizeof(double)));
     const size_t np = (size_t)md.nseg * PGAS_SEG;
-    HIPCHK(c, hipMalloc(&c->la_buf, (size_t)md.T * np * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->h_buf, (size_t)md.T * np * sizeof(double)));
-    HIPCHK(c, hipMalloc(&c->ln_buf, (size_t)md.T * np * sizeof(double)));
+    const size_t bb = c->trace_block_bytes ? c->trace_block_bytes : (blocked ? PG_TRACE_BLOCK_BYTES : 0);
+    int rc = alloc_rows(c, &c->rs[PG_RB_X], md.T, (size_t)md.N * md.nx * sizeof(double), bb);
+    if (!rc) rc = alloc_rows(c, &c->rs[PG_RB_ANC], md.T > 1 ? md.T - 1 : 1, (size_t)md.N * sizeof(int32_t), bb);
+    for (int k : {PG_RB_LA, PG_RB_H, PG_RB_LN})
+        if (!rc) rc = alloc_rows(c, &c->rs[k], md.T, np * sizeof(double), bb);
+    if (rc) {
+        for (RowStore& r : c->rs) r.release();
+        return rc;
+    }
+    HIPCHK(c, hipMalloc(&c->logw_last, (size_t)md.N * sizeof(double)));
     if (c->keep_logw) {
         HIPCHK(c, hipMalloc(&c->logw_trace, (size_t)md.T * md.N * sizeof(double)));
         HIPCHK(c, hipMemset(c->logw_trace, 0, (size_t)md.T * md.N * sizeof(double)));
     }
+    c->have_traces = true;
     install_own_peers(c);
     return PGAS_OK;
 }
@@ -613,21 +732,33 @@ static int launch_propagate(pgas_ctx* c, uint64_t seed, int t0, int t1, const do
         if (need > 64 * 1024) FAIL(c, PGAS_E_ARG, "k_propagate: coefficient tensor of %zu bytes does not fit the LDS budget", need);
         lds = lds > need ? lds : need;
     }
-    const prop_fn prop = (t1 == t0 + 1 && c->var.prop_one) ? c->var.prop_one : c->var.prop;
-    if (timed) {
-        while ((int)c->evp.size() < c->evp_used + 2) {
-            hipEvent_t e;
-            HIPCHK(c, hipEventCreate(&e));
-            c->evp.push_back(e);
+    // a launch writes rows [ta, tb) that lie in ONE block of every trace (blocks are power-of-two runs of rows, the hand-off rows'
+    // at least as long as the state rows'): a chunk that straddles a block boundary is split there
+    const int sh = std::min(c->rs[PG_RB_X].shift, c->rs[PG_RB_LA].shift);
+    for (int ta = t0; ta < t1;) {
+        const int tb = std::min(t1, ((ta >> sh) + 1) << sh);
+        const prop_fn prop = (tb == ta + 1 && c->var.prop_one) ? c->var.prop_one : c->var.prop;
+        const double* x_prev = (const double*)c->rs[PG_RB_X].row(ta - 1);
+        double* x_rows = (double*)c->rs[PG_RB_X].row(ta);
+        double* la = (double*)c->rs[PG_RB_LA].row(ta);
+        double* h = (double*)c->rs[PG_RB_H].row(ta);
+        double* ln = (double*)c->rs[PG_RB_LN].row(ta);
+        if (timed) {
+            while ((int)c->evp.size() < c->evp_used + 2) {
+                hipEvent_t e;
+                HIPCHK(c, hipEventCreate(&e));
+                c->evp.push_back(e);
+            }
+            // start/stop events bound to the dispatch itself: they carry the kernel's own begin/end timestamps
+            hipExtLaunchKernelGGL(prop, grid, blk, lds, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, c->md, c->tp, seed, ta, tb, x_prev, x_rows,
+                                  ref_dev, la, h, ln);
+            c->evp_used += 2;
+        } else {
+            hipLaunchKernelGGL(prop, grid, blk, lds, st, c->md, c->tp, seed, ta, tb, x_prev, x_rows, ref_dev, la, h, ln);
         }
-        // start/stop events bound to the dispatch itself: they carry the kernel's own begin/end timestamps
-        hipExtLaunchKernelGGL(prop, grid, blk, lds, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, c->md, c->tp, seed, t0, t1, c->x_trace,
-                              ref_dev, c->la_buf, c->h_buf, c->ln_buf);
-        c->evp_used += 2;
-    } else {
-        hipLaunchKernelGGL(prop, grid, blk, lds, st, c->md, c->tp, seed, t0, t1, c->x_trace, ref_dev, c->la_buf, c->h_buf, c->ln_buf);
+        KCHK(c, "k_propagate");
+        ta = tb;
     }
-    KCHK(c, "k_propagate");
     return PGAS_OK;
 }
 
@@ -715,8 +846,13 @@ static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int 
                     rc = shard_all_gather(c, t & 1, sB);   // the one collective of the step, stream-ordered: no host round trip
                     if (rc) return rc;
                 }
-                rc = launch_groups(c, c->sb[t & 1], 2, sB);
-                if (rc) return rc;
+                if (sweep_is_abs(c)) {
+                    hipLaunchKernelGGL(k_groups_abs, dim3(1), dim3(64 * PG_ABS_WAVES), 0, sB, md.nseg_g, 2, c->sb[t & 1]);
+                    KCHK(c, "k_groups_abs");
+                } else {
+                    rc = launch_groups(c, c->sb[t & 1], 2, sB);
+                    if (rc) return rc;
+                }
             }
         }
         if (lead > 0) HIPCHK(c, hipEventRecord(c->ev_bdone[gi], sB));
@@ -744,9 +880,7 @@ static int run_final(pgas_ctx* c, uint64_t seed, double* traj_dev, hipStream_t s
     if (rc) return rc;
     rc = launch_count(c, sf, T & 1, 1, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, st, md.N, T, md.nx, c->x_trace, c->anc_trace, c->peers, sf.hdr, traj_dev);
-    KCHK(c, "k_backtrace");
-    return PGAS_OK;
+    return launch_backtrace(c, sf.hdr, traj_dev, st);
 }
 
 int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_dev, void* stream) {
@@ -755,15 +889,16 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_sweep: call pgas_set_params first");
     if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_sweep: this context is a shard; drive it with pgas_shard_sweep");
     DeviceGuard guard(c->device);
-    int rc = ensure_traces(c);
+    int rc = ensure_traces(c, false);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     const DevModel& md = c->md;
     const int N = md.N, T = md.T, nx = md.nx;
     const size_t row = (size_t)N * nx;
     const dim3 grid(md.nseg), blk(PG_BLK);
+    auto xrow = [&](int t) { return (double*)c->rs[PG_RB_X].row(t); };
 
-    hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, c->x_trace);
+    hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, xrow(0));
     KCHK(c, "k_init");
     c->ev_used = 0;
     c->evp_used = 0;
@@ -777,7 +912,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
         for (int t = 1; t < T; ++t) {
             const double* lw_prev = t == 1 ? (const double*)nullptr : (c->logw_trace ? c->logw_trace + (size_t)(t - 1) * N : c->logw_last);
             double* lw_out = c->logw_trace ? c->logw_trace + (size_t)t * N : c->logw_last;
-            hipLaunchKernelGGL(c->var.front, grid, blk, 0, st, md, c->tp, t, seed, c->x_trace + (size_t)(t - 1) * row, lw_prev, ref_dev + (size_t)t * nx, 1,
+            hipLaunchKernelGGL(c->var.front, grid, blk, 0, st, md, c->tp, t, seed, xrow(t - 1), lw_prev, ref_dev + (size_t)t * nx, 1,
                                c->aux_buf, c->sb[0]);
             KCHK(c, "k_front");
             rc = launch_groups(c, c->sb[0], 2, st);
@@ -785,7 +920,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
             rc = launch_count(c, c->sb[0], 0, 0, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), st);
             if (rc) return rc;
             hipLaunchKernelGGL(c->back_corrected, grid, blk, 0, st, md, c->tp, t, seed, pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t),
-                               c->aux_buf, ref_dev + (size_t)t * nx, c->sb[0], pr, c->anc_trace + (size_t)(t - 1) * N, c->x_trace + (size_t)t * row, lw_out);
+                               c->aux_buf, ref_dev + (size_t)t * nx, c->sb[0], pr, (int32_t*)c->rs[PG_RB_ANC].row(t - 1), xrow(t), lw_out);
             KCHK(c, "k_back_corrected");
         }
         if (c->logw_trace)
@@ -805,18 +940,43 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
 
 int pgas_get_traces(pgas_ctx* c, double** x_trace, int32_t** anc_trace, double** logw_last, double** logw_trace) {
     if (!c) return PGAS_E_ARG;
-    if (!c->x_trace) FAIL(c, PGAS_E_STATE, "pgas_get_traces: no sweep has run");
-    if (x_trace) *x_trace = c->x_trace;
-    if (anc_trace) *anc_trace = c->anc_trace;
+    if (!c->have_traces) FAIL(c, PGAS_E_STATE, "pgas_get_traces: no sweep has run");
+    if ((x_trace || anc_trace) && !c->rs[PG_RB_X].contiguous)
+        FAIL(c, PGAS_E_STATE, "pgas_get_traces: this context keeps its traces in row blocks (sharded, or PGAS_OPT_TRACE_BLOCK_BYTES): use pgas_trace_layout / pgas_trace_row");
+    if (x_trace) *x_trace = (double*)c->rs[PG_RB_X].blk[0];
+    if (anc_trace) *anc_trace = (int32_t*)c->rs[PG_RB_ANC].blk[0];
     if (logw_last) *logw_last = c->logw_last;
     if (logw_trace) *logw_trace = c->logw_trace;
+    return PGAS_OK;
+}
+
+/* Block layout of trace `kind` (PGAS_TRACE_*): info4 = {rows, rows per block (a power of two), blocks, bytes per row}.
+ * Row t lives in block t / rows_per_block at row t % rows_per_block; pgas_trace_row returns its device pointer. */
+int pgas_trace_layout(pgas_ctx* c, int32_t kind, int64_t* info4) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->have_traces) FAIL(c, PGAS_E_STATE, "pgas_trace_layout: no traces yet (run a sweep or pgas_shard_setup first)");
+    if (kind < 0 || kind >= PG_RB_NKIND || !info4) FAIL(c, PGAS_E_ARG, "pgas_trace_layout: bad argument");
+    const RowStore& s = c->rs[kind];
+    info4[0] = s.rows;
+    info4[1] = s.contiguous ? s.rows : ((int64_t)1 << s.shift);
+    info4[2] = s.nblk;
+    info4[3] = (int64_t)s.row_bytes;
+    return PGAS_OK;
+}
+
+int pgas_trace_row(pgas_ctx* c, int32_t kind, int32_t t, void** ptr) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->have_traces) FAIL(c, PGAS_E_STATE, "pgas_trace_row: no traces yet");
+    if (kind < 0 || kind >= PG_RB_NKIND || !ptr || t < 0 || t >= c->rs[kind < 0 || kind >= PG_RB_NKIND ? 0 : kind].rows)
+        FAIL(c, PGAS_E_ARG, "pgas_trace_row: bad argument");
+    *ptr = c->rs[kind].row(t);
     return PGAS_OK;
 }
 
 int pgas_last_final_index(pgas_ctx* c, int64_t* idx, void* stream) {
     if (!c) return PGAS_E_ARG;
     if (!idx) FAIL(c, PGAS_E_ARG, "pgas_last_final_index: NULL argument");
-    if (!c->x_trace) FAIL(c, PGAS_E_STATE, "pgas_last_final_index: no sweep has run");
+    if (!c->have_traces) FAIL(c, PGAS_E_STATE, "pgas_last_final_index: no sweep has run");
     DeviceGuard guard(c->device);
     HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
     UpperHdr h;
@@ -876,6 +1036,12 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         c->prop_lds = (int)value;
         return PGAS_OK;
     }
+    if (option == PGAS_OPT_TRACE_BLOCK_BYTES) {
+        if (value < 0) FAIL(c, PGAS_E_ARG, "pgas_set_option: block bytes must be >= 0");
+        if (c->have_traces) FAIL(c, PGAS_E_STATE, "pgas_set_option: the traces are already allocated");
+        c->trace_block_bytes = (size_t)value;
+        return PGAS_OK;
+    }
     if (option == PGAS_OPT_MNIW_VALU) {
         c->mniw_valu = value ? 1 : 0;
         return PGAS_OK;
@@ -920,7 +1086,7 @@ int pgas_get_launch_info(pgas_ctx* c, int32_t* info4) {
     if (!c) return PGAS_E_ARG;
     if (!info4) FAIL(c, PGAS_E_ARG, "pgas_get_launch_info: NULL argument");
     info4[0] = c->last_chunk;
-    info4[1] = sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0);
+    info4[1] = sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : (sweep_is_abs(c) ? 3 : 0));
     info4[2] = c->md.JP;
     info4[3] = c->var_P;
     return PGAS_OK;
@@ -994,7 +1160,15 @@ int pgas_shard_setup(pgas_ctx* c, int32_t rank, int32_t world) {
     if (c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_setup: already set up");
     if (c->corrected) FAIL(c, PGAS_E_STATE, "pgas_shard_setup: the corrected mode is not available on a sharded context");
     DeviceGuard guard(c->device);
-    int rc = ensure_traces(c);
+    if (c->have_traces && c->rs[PG_RB_X].contiguous) {
+        // an unsharded sweep ran on this context before: its traces are single allocations; a shard's are row blocks (IPC export)
+        HIPCHK(c, hipDeviceSynchronize());
+        for (RowStore& r : c->rs) r.release();
+        hipFree(c->logw_last); hipFree(c->logw_trace);
+        c->logw_last = c->logw_trace = nullptr;
+        c->have_traces = false;
+    }
+    int rc = ensure_traces(c, true);
     if (rc) return rc;
     // allocate everything first, commit the context's state only when nothing can fail any more
     const int nsegp = c->sb[0].nsegp, nseg_g = c->md.nseg * world, nsegp_g = (nseg_g + 63) / 64 * 64;
@@ -1022,8 +1196,7 @@ int pgas_shard_setup(pgas_ctx* c, int32_t rank, int32_t world) {
     md.Ng = md.N * world;
     md.nseg_g = nseg_g;
     for (int r = 0; r < PG_MAX_RANKS; ++r) {   // forget the single-device table: every rank must be installed again
-        c->peers.la[r] = c->peers.h[r] = c->peers.ln[r] = c->peers.x[r] = nullptr;
-        c->peers.anc[r] = nullptr;
+        for (int k = 0; k < PG_RB_NKIND; ++k) c->peer_blk[r][k].clear();
         c->peer_c1[0][r] = c->peer_c1[1][r] = c->peer_c2[0][r] = c->peer_c2[1][r] = nullptr;
     }
     c->peers.world = world; c->peers.nseg_l = md.nseg; c->peers.Nl = md.N;
@@ -1040,14 +1213,16 @@ int pgas_shard_setup(pgas_ctx* c, int32_t rank, int32_t world) {
     return PGAS_OK;
 }
 
-/* out[17]: c1[0], c1[1], la_buf, h_buf, ln_buf, x_trace, anc_trace (the seven buffers peers read; pgas_ipc_export indices),
- *          c2[0], c2[1] (unused by the sweep), segk_w[0], segk_w[1], segs_w[0], segs_w[1], segk_g[0], segk_g[1], segs_g[0], segs_g[1];
+/* out[17]: c1[0], c1[1], then the FIRST block of la, h, ln, x, anc (the seven buffers peers read; every block of them is listed by
+ *          pgas_shard_layout / pgas_shard_block), c2[0], c2[1] (unused by the sweep), segk_w[0], segk_w[1], segs_w[0], segs_w[1],
+ *          segk_g[0], segk_g[1], segs_g[0], segs_g[1];
  * sizes[3]: nsegp (local padded segments), N_local, T */
 int pgas_shard_buffers(pgas_ctx* c, void** out, int64_t* sizes) {
     if (!c) return PGAS_E_ARG;
     if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_buffers: call pgas_shard_setup first");
     if (!out || !sizes) FAIL(c, PGAS_E_ARG, "pgas_shard_buffers: NULL argument");
-    out[0] = c->sb[0].c1; out[1] = c->sb[1].c1; out[2] = c->la_buf; out[3] = c->h_buf; out[4] = c->ln_buf; out[5] = c->x_trace; out[6] = c->anc_trace;
+    out[0] = c->sb[0].c1; out[1] = c->sb[1].c1;
+    out[2] = c->rs[PG_RB_LA].blk[0]; out[3] = c->rs[PG_RB_H].blk[0]; out[4] = c->rs[PG_RB_LN].blk[0]; out[5] = c->rs[PG_RB_X].blk[0]; out[6] = c->rs[PG_RB_ANC].blk[0];
     out[7] = c->sb[0].c2; out[8] = c->sb[1].c2;
     out[9] = c->sb[0].segk_w; out[10] = c->sb[1].segk_w; out[11] = c->sb[0].segs_w; out[12] = c->sb[1].segs_w;
     out[13] = c->segk_g[0]; out[14] = c->segk_g[1]; out[15] = c->segs_g[0]; out[16] = c->segs_g[1];
@@ -1055,25 +1230,71 @@ int pgas_shard_buffers(pgas_ctx* c, void** out, int64_t* sizes) {
     return PGAS_OK;
 }
 
-/* bufs[7]: the peer's c1[0], c1[1], la_buf, h_buf, ln_buf, x_trace, anc_trace as mapped into THIS process */
-int pgas_shard_set_peer(pgas_ctx* c, int32_t peer, const void* const* bufs) {
+// peer-visible buffer `which` (0, 1: the cumsum of scan buffer 0 / 1; 2..6: la, h, ln, x, anc) -> trace kind, or -1 for the cumsums
+static int shard_which_kind(int which) {
+    static const int k[7] = {-1, -1, PG_RB_LA, PG_RB_H, PG_RB_LN, PG_RB_X, PG_RB_ANC};
+    return k[which];
+}
+
+/* Blocks of peer-visible buffer `which` (0..6 as in pgas_shard_buffers): info2 = {number of blocks, rows per block}.  The cumsums are
+ * one block each; the traces are row blocks of at most 1 GiB (PGAS_OPT_TRACE_BLOCK_BYTES), the same layout on every rank. */
+int pgas_shard_layout(pgas_ctx* c, int32_t which, int64_t* info2) {
     if (!c) return PGAS_E_ARG;
-    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_set_peer: call pgas_shard_setup first");
-    if (peer < 0 || peer >= c->world || !bufs) FAIL(c, PGAS_E_ARG, "pgas_shard_set_peer: bad argument");
-    for (int k = 0; k < 7; ++k)
-        if (!bufs[k]) FAIL(c, PGAS_E_ARG, "pgas_shard_set_peer: buffer %d of rank %d is NULL", k, peer);
-    c->peer_c1[0][peer] = (const uint64_t*)bufs[0]; c->peer_c1[1][peer] = (const uint64_t*)bufs[1];
-    c->peers.la[peer] = (const double*)bufs[2]; c->peers.h[peer] = (const double*)bufs[3]; c->peers.ln[peer] = (const double*)bufs[4];
-    c->peers.x[peer] = (const double*)bufs[5]; c->peers.anc[peer] = (const int32_t*)bufs[6];
+    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_layout: call pgas_shard_setup first");
+    if (which < 0 || which > 6 || !info2) FAIL(c, PGAS_E_ARG, "pgas_shard_layout: bad argument");
+    const int k = shard_which_kind(which);
+    info2[0] = k < 0 ? 1 : c->rs[k].nblk;
+    info2[1] = k < 0 ? 1 : ((int64_t)1 << c->rs[k].shift);
+    return PGAS_OK;
+}
+
+/* Device pointer and size of block `blk` of this rank's buffer `which`. */
+int pgas_shard_block(pgas_ctx* c, int32_t which, int32_t blk, void** ptr, int64_t* bytes) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_block: call pgas_shard_setup first");
+    if (which < 0 || which > 6 || !ptr) FAIL(c, PGAS_E_ARG, "pgas_shard_block: bad argument");
+    const int k = shard_which_kind(which);
+    if (blk < 0 || blk >= (k < 0 ? 1 : c->rs[k].nblk)) FAIL(c, PGAS_E_ARG, "pgas_shard_block: buffer %d has no block %d", which, blk);
+    if (k < 0) {
+        *ptr = c->sb[which].c1;
+        if (bytes) *bytes = (int64_t)((size_t)c->md.nseg * PGAS_SEG * sizeof(uint64_t));
+    } else {
+        *ptr = c->rs[k].blk[blk];
+        if (bytes) *bytes = (int64_t)((size_t)c->rs[k].rows_in_block(blk) * c->rs[k].row_bytes);
+    }
+    return PGAS_OK;
+}
+
+/* Block `blk` of rank `peer`'s buffer `which` as mapped into THIS process (same process: the pointer itself; another process:
+ * what pgas_ipc_open returned for the handle of pgas_ipc_export(which, blk) on that rank). */
+int pgas_shard_set_peer_block(pgas_ctx* c, int32_t peer, int32_t which, int32_t blk, const void* ptr) {
+    if (!c) return PGAS_E_ARG;
+    if (!c->sharded) FAIL(c, PGAS_E_STATE, "pgas_shard_set_peer_block: call pgas_shard_setup first");
+    if (peer < 0 || peer >= c->world || which < 0 || which > 6 || !ptr) FAIL(c, PGAS_E_ARG, "pgas_shard_set_peer_block: bad argument");
+    const int k = shard_which_kind(which);
+    if (blk < 0 || blk >= (k < 0 ? 1 : c->rs[k].nblk)) FAIL(c, PGAS_E_ARG, "pgas_shard_set_peer_block: buffer %d has no block %d", which, blk);
+    if (k < 0) {
+        c->peer_c1[which][peer] = (const uint64_t*)ptr;
+    } else {
+        auto& v = c->peer_blk[peer][k];
+        if ((int)v.size() != c->rs[k].nblk) v.assign((size_t)c->rs[k].nblk, nullptr);
+        v[blk] = (const char*)ptr;
+        c->bt_dirty = true;
+    }
     return PGAS_OK;
 }
 
 static int shard_ready(pgas_ctx* c, const char* who) {
     if (!c->sharded) FAIL(c, PGAS_E_STATE, "%s: call pgas_shard_setup first", who);
     if (!c->have_params) FAIL(c, PGAS_E_STATE, "%s: call pgas_set_params first", who);
-    for (int r = 0; r < c->world; ++r)
-        if (!c->peers.la[r] || !c->peers.h[r] || !c->peers.ln[r] || !c->peers.x[r] || !c->peers.anc[r] || !c->peer_c1[0][r] || !c->peer_c1[1][r])
-            FAIL(c, PGAS_E_STATE, "%s: buffers of rank %d not installed (pgas_shard_set_peer)", who, r);
+    for (int r = 0; r < c->world; ++r) {
+        bool ok = c->peer_c1[0][r] && c->peer_c1[1][r];
+        for (int k = 0; k < PG_RB_NKIND && ok; ++k) {
+            ok = (int)c->peer_blk[r][k].size() == c->rs[k].nblk;
+            for (size_t b = 0; ok && b < c->peer_blk[r][k].size(); ++b) ok = c->peer_blk[r][k][b] != nullptr;
+        }
+        if (!ok) FAIL(c, PGAS_E_STATE, "%s: buffers of rank %d not installed (pgas_shard_set_peer_block)", who, r);
+    }
     return PGAS_OK;
 }
 
@@ -1089,7 +1310,7 @@ int pgas_shard_run(pgas_ctx* c, int32_t phase, int32_t t, int32_t t_aux, uint64_
     switch (phase) {
     case PGAS_SHARD_INIT:
         if (!ref_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_run(INIT): ref_dev == NULL");
-        hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, c->x_trace);
+        hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].row(0));
         KCHK(c, "k_init");
         return PGAS_OK;
     case PGAS_SHARD_PROPAGATE:  // time steps [t, t_aux)
@@ -1111,9 +1332,7 @@ int pgas_shard_run(pgas_ctx* c, int32_t phase, int32_t t, int32_t t_aux, uint64_
         return launch_count(c, c->sb[T & 1], T & 1, 1, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), st);
     case PGAS_SHARD_BACKTRACE:
         if (!traj_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_run(BACKTRACE): traj_dev == NULL");
-        hipLaunchKernelGGL(k_backtrace, dim3(1), dim3(64), 0, st, N, T, md.nx, c->x_trace, c->anc_trace, c->peers, c->sb[T & 1].hdr, traj_dev);
-        KCHK(c, "k_backtrace");
-        return PGAS_OK;
+        return launch_backtrace(c, c->sb[T & 1].hdr, traj_dev, st);
     default:
         FAIL(c, PGAS_E_ARG, "pgas_shard_run: unknown phase %d", phase);
     }
@@ -1185,7 +1404,7 @@ int pgas_shard_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* 
     hipStream_t st = (hipStream_t)stream;
     const DevModel& md = c->md;
     const int T = md.T;
-    hipLaunchKernelGGL(c->init, dim3((md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, md, seed, c->d_m0L0, ref_dev, c->x_trace);
+    hipLaunchKernelGGL(c->init, dim3((md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, md, seed, c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].row(0));
     KCHK(c, "k_init");
     c->ev_used = 0;
     c->evp_used = 0;
@@ -1225,15 +1444,18 @@ int32_t pgas_hip_runtime_version(void) {
     return hipRuntimeGetVersion(&v) == hipSuccess ? v : -1;
 }
 
-int pgas_ipc_export(pgas_ctx* c, int32_t which, void* handle64) {
+int pgas_ipc_export(pgas_ctx* c, int32_t which, int32_t blk, void* handle64) {
     if (!c) return PGAS_E_ARG;
-    void* bufs[17]; int64_t sz[3];
-    int rc = pgas_shard_buffers(c, bufs, sz);
+    if (!handle64) FAIL(c, PGAS_E_ARG, "pgas_ipc_export: NULL argument");
+    void* p = nullptr;
+    int64_t bytes = 0;
+    int rc = pgas_shard_block(c, which, blk, &p, &bytes);
     if (rc) return rc;
-    if (which < 0 || which > 6 || !handle64) FAIL(c, PGAS_E_ARG, "pgas_ipc_export: bad argument");
+    // the blocks are sized to stay below this (pgas_shard_setup); a caller-chosen PGAS_OPT_TRACE_BLOCK_BYTES may not
+    if (bytes >= ((int64_t)1 << 31)) FAIL(c, PGAS_E_ARG, "pgas_ipc_export: block of %lld bytes; blocks of 2 GiB and more cannot be mapped by every HIP runtime", (long long)bytes);
     static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
     DeviceGuard guard(c->device);
-    HIPCHK(c, hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, bufs[which]));
+    HIPCHK(c, hipIpcGetMemHandle((hipIpcMemHandle_t*)handle64, p));
     return PGAS_OK;
 }
 int pgas_ipc_open(pgas_ctx* c, const void* handle64, void** ptr) {

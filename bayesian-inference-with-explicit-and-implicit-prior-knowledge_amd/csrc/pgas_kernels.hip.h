@@ -104,15 +104,26 @@ struct UpperHdr {      // small per-scan-buffer results
 };
 
 #define PG_MAX_RANKS 8
-struct Peers {         // device pointers of every rank's buffers (xGMI peer mappings); world == 1: this device only
+struct Peers {         // device pointers of every rank's scan buffers (xGMI peer mappings); world == 1: this device only
     const uint64_t* c1[PG_MAX_RANKS];   // the c1 buffer being READ this launch
     const uint64_t* c2[PG_MAX_RANKS];   // step API only (pgas_step keeps the ancestor cumsum)
-    const double* la[PG_MAX_RANKS];     // la_buf bases (row offsets are added in the kernel)
-    const double* h[PG_MAX_RANKS];      // h_buf bases
-    const double* ln[PG_MAX_RANKS];     // ln_buf bases
-    const double* x[PG_MAX_RANKS];      // x_trace bases
-    const int32_t* anc[PG_MAX_RANKS];   // anc_trace bases
     int32_t world, nseg_l, Nl;          // ranks, segments per rank, particles per rank
+};
+
+// The traces (x, la, h, ln, ancestors) are stored as ROW BLOCKS: consecutive time rows in allocations of at most 1 GiB, so that every
+// block can be exported to the other ranks' processes with hipIpcGetMemHandle (the HIP runtime bundled with PyTorch never returns
+// from hipIpcOpenMemHandle for an allocation of 2 GiB or more).  Kernels that touch a handful of rows get the row pointers from
+// the host, per launch (StepArgs / AncIn, k_propagate's arguments); only the ancestor chase walks every row of every rank and
+// reads the block table itself.
+#define PG_RB_X 0
+#define PG_RB_LA 1
+#define PG_RB_H 2
+#define PG_RB_LN 3
+#define PG_RB_ANC 4
+#define PG_RB_NKIND 5
+struct BtTab {         // k_backtrace: blk[(rank * 2 + (0: x, 1: anc)) * nblk_max + b] = base of block b (rows b << shift ...) on that rank
+    const void* const* blk;
+    int32_t nblk_max, shift_x, shift_anc, entries;
 };
 
 struct ScanBufs {      // per-step scan scratch (device)
@@ -130,6 +141,9 @@ struct ScanBufs {      // per-step scan scratch (device)
     double* tab_e;     // (2, nsegp_g) per-segment records written by k_groups: exclusive prefix inside the group,
     double* tab_sc;    //              scale 2^(kref - KG),
     double* tab_m;     //              running maximum of the segment-end values inside the group
+    double* abs_cm;    // (2, nsegp_g) k_groups_abs: running maximum at the segment's end on the scale of the total S (tab_m then holds the
+    int32_t* abs_dexp; //              running maximum BEFORE the segment), log2 of the segment's scale (PG_DEXP_ZERO: scale 0),
+    double* abs_grp;   // (2, 4, 16)   per group E, sigma, CM of the group before; [3][0] = S
     double* grp_K;     // (2, PG_MAX_GRP) group references KG
     double* grp_T;     // (2, PG_MAX_GRP) group totals TG
     unsigned* grp_cnt; // (PG_MAX_GRP) arrival counters of k_step's in-launch group scans (zero between uses)
@@ -930,9 +944,10 @@ __device__ __forceinline__ void propagate_group(const DevModel& md, const TransP
 // loaded right before its pass instead of being held for the whole launch (8 particles x 2 doubles = 32 VGPRs less).
 template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT, bool ONE = false>
 __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParams tp, uint64_t seed, int t0, int t1,
-                                                          double* __restrict__ x_trace, const double* __restrict__ ref,
-                                                          double* __restrict__ la_buf, double* __restrict__ h_buf,
-                                                          double* __restrict__ ln_buf) {
+                                                          const double* __restrict__ x_prev /* row t0-1 */, double* __restrict__ x_rows /* rows t0 ... */,
+                                                          const double* __restrict__ ref,
+                                                          double* __restrict__ la_rows, double* __restrict__ h_rows,
+                                                          double* __restrict__ ln_rows /* rows t0 ... of the hand-off buffers */) {
     const int tid = threadIdx.x;
     const size_t row = (size_t)md.N * NX, np = (size_t)md.nseg * PGAS_SEG;
     // 3-D bases: the coefficient tensor (J0 x J1 x JIN x NX doubles, 23 KB for the 729-function bases) is copied to LDS once per launch
@@ -956,15 +971,15 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
             if (pi >= (size_t)md.N) pi = md.N - 1;
             if constexpr (NX == 2) {
 #ifdef PG_NT_LOADS
-                const pg_nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const pg_nt_d2*>(x_trace + (size_t)(t0 - 1) * row) + pi);
+                const pg_nt_d2 v = __builtin_nontemporal_load(reinterpret_cast<const pg_nt_d2*>(x_prev) + pi);
 #else
-                const double2 v = reinterpret_cast<const double2*>(x_trace + (size_t)(t0 - 1) * row)[pi];
+                const double2 v = reinterpret_cast<const double2*>(x_prev)[pi];
 #endif
                 xr[0] = v.x;
                 xr[1] = v.y;
             } else {
 #pragma unroll
-                for (int k = 0; k < NX; ++k) xr[k] = x_trace[(size_t)(t0 - 1) * row + pi * NX + k];
+                for (int k = 0; k < NX; ++k) xr[k] = x_prev[pi * NX + k];
             }
         };
         double xv[ONE ? 1 : PPT][NX];
@@ -978,7 +993,8 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
             double rf[NX];
 #pragma unroll
             for (int k = 0; k < NX; ++k) rf[k] = ref[(size_t)t * NX + k];
-            double* __restrict__ xt = x_trace + (size_t)t * row;
+            double* __restrict__ xt = x_rows + (size_t)(t - t0) * row;
+            const size_t hrow = (size_t)(t - t0) * np;
             // ONE: kept rolled -- four unrolled copies of the pass are 35 KB of code, and k_step's 60 KB run beside it on an
             // instruction cache of 64 KB per CU pair
             constexpr int kUnroll = ONE ? 1 : PPT / P;
@@ -1021,13 +1037,13 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
                         }
                     }
 #ifdef PG_NT_H
-                    __builtin_nontemporal_store(la[p], &la_buf[(size_t)t * np + pi]);
-                    __builtin_nontemporal_store(h[p], &h_buf[(size_t)t * np + pi]);
-                    __builtin_nontemporal_store(ln[p], &ln_buf[(size_t)t * np + pi]);
+                    __builtin_nontemporal_store(la[p], &la_rows[hrow + pi]);
+                    __builtin_nontemporal_store(h[p], &h_rows[hrow + pi]);
+                    __builtin_nontemporal_store(ln[p], &ln_rows[hrow + pi]);
 #else
-                    la_buf[(size_t)t * np + pi] = la[p];
-                    h_buf[(size_t)t * np + pi] = h[p];
-                    ln_buf[(size_t)t * np + pi] = ln[p];
+                    la_rows[hrow + pi] = la[p];
+                    h_rows[hrow + pi] = h[p];
+                    ln_rows[hrow + pi] = ln[p];
 #endif
                     if constexpr (!ONE) {
 #pragma unroll
@@ -1057,20 +1073,28 @@ __global__ __launch_bounds__(PG_BLK) void k_segscan(int N, const double* __restr
 // ------------------------------------------------------------------------------------------
 // k_backtrace: reconstruct_trajectory (src/Filtering.py:40-55), one lane chases the ancestors
 // ------------------------------------------------------------------------------------------
-__global__ void k_backtrace(int Nl, int T, int nx, const double* __restrict__ x_trace, const int32_t* __restrict__ anc_trace,
-                            Peers pr, const UpperHdr* __restrict__ hdr, double* __restrict__ traj) {
-    // b is a GLOBAL particle index; its row lives on rank b / Nl (single device: rank 0, Nl = N)
+__global__ void k_backtrace(int Nl, int T, int nx, BtTab tab, int world, const UpperHdr* __restrict__ hdr, double* __restrict__ traj) {
+    // b is a GLOBAL particle index; its row lives on rank b / Nl (single device: rank 0, Nl = N).  The block table goes to LDS
+    // first when it fits (it is on the dependent chain of every hop), then one lane chases.
+    extern __shared__ const void* pg_bt_lds[];
+    const bool in_lds = tab.entries <= 2048;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < tab.entries; i += blockDim.x) pg_bt_lds[i] = tab.blk[i];
+        __syncthreads();
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const void* const* blk = in_lds ? pg_bt_lds : tab.blk;
+    const int mx = (1 << tab.shift_x) - 1, ma = (1 << tab.shift_anc) - 1;
     int64_t b = hdr->final_idx;
     for (int i = T - 1; i >= 0; --i) {
-        const int r = pr.world > 1 ? (int)(b / Nl) : 0;
+        const int r = world > 1 ? (int)(b / Nl) : 0;
         const int64_t bl = b - (int64_t)r * Nl;
-        const double* __restrict__ xr = pr.world > 1 ? pr.x[r] : x_trace;
-        for (int k = 0; k < nx; ++k) traj[(size_t)i * nx + k] = xr[((size_t)i * Nl + bl) * nx + k];
+        const double* __restrict__ xr = (const double*)blk[(size_t)(r * 2) * tab.nblk_max + (i >> tab.shift_x)] + (size_t)(i & mx) * Nl * nx;
+        for (int k = 0; k < nx; ++k) traj[(size_t)i * nx + k] = xr[(size_t)bl * nx + k];
         if (i > 0) {
-            const int32_t* __restrict__ ar = pr.world > 1 ? pr.anc[r] : anc_trace;
-            // ancestor of particle b of time i, stored in row i-1 ... but row i-1 is indexed by the CHILD (time i) particle
-            b = ar[(size_t)(i - 1) * Nl + bl];
+            // ancestor of particle b of time i: row i-1 of the ancestor trace, indexed by the CHILD (time i) particle
+            const int32_t* __restrict__ ar = (const int32_t*)blk[(size_t)(r * 2 + 1) * tab.nblk_max + ((i - 1) >> tab.shift_anc)] + (size_t)((i - 1) & ma) * Nl;
+            b = ar[bl];
         }
     }
 }

@@ -140,10 +140,76 @@ __global__ __launch_bounds__(256) void k_groups(int nseg, int ncdf, ScanBufs sb)
     group_records_wave(sb, nseg, w / n1, w % n1, false);
 }
 
+// k_groups_abs: the same records for a device whose CDF fits ONE search window (nseg <= 1024, i.e. <= 16 groups), in ABSOLUTE form.
+// One workgroup of 16 waves: wave w scans group w, the (KG, TG) records meet in LDS, every wave repeats the (16-lane) top scan
+// and then finishes its own group: what k_step's window needs per segment -- running maximum cm at the segment's end on the scale
+// of the total S, exclusive prefix e, running maximum mp before it, log2 of the scale -- and per group (E, sigma, CM before), plus S.
+// A k_step workgroup then fills its window with ONE round of independent loads and no scan of its own (window mode PG_WM_ABS);
+// with k_groups it needs the group records, a top scan by one wave and a second, dependent round of loads.  Same values bit for bit.
+#define PG_ABS_WAVES (PG_WIN_SEG / PG_GRP)
+__global__ __launch_bounds__(64 * PG_ABS_WAVES) void k_groups_abs(int nseg, int ncdf, ScanBufs sb) {
+    __shared__ double sK[2][PG_ABS_WAVES], sT[2][PG_ABS_WAVES];
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n1 = (nseg + PG_GRP - 1) / PG_GRP;
+    const int b = g * PG_GRP + lane;
+    double e[2], sc[2], m[2];
+#pragma unroll
+    for (int cdf = 0; cdf < 2; ++cdf) {
+        if (cdf >= ncdf) break;   // uniform
+        double kk = -__builtin_inf();
+        uint64_t ss = 0;
+        if (b < nseg) {
+            const size_t at = partial_at(sb, cdf, b);
+            kk = sb.segk[at];
+            ss = sb.segs[at];
+        }
+        double Kg;
+        group_scan_wave(kk, ss, e[cdf], sc[cdf], m[cdf], Kg);
+        int nb = nseg - g * PG_GRP;
+        nb = nb < 1 ? 1 : (nb > PG_GRP ? PG_GRP : nb);
+        const double Tg = readlane_f64(m[cdf], nb - 1);
+        if (lane == 0) {
+            sK[cdf][g] = g < n1 ? Kg : -__builtin_inf();
+            sT[cdf][g] = g < n1 ? Tg : 0.0;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cdf = 0; cdf < 2; ++cdf) {
+        if (cdf >= ncdf) break;   // uniform
+        const double Kg2[2] = {lane < n1 ? sK[cdf][lane & (PG_ABS_WAVES - 1)] : -__builtin_inf(), -__builtin_inf()};
+        const double Tg2[2] = {lane < n1 ? sT[cdf][lane & (PG_ABS_WAVES - 1)] : 0.0, 0.0};
+        double E[2], sig[2], CM[2];
+        const double S = top_scan_wave(n1, Kg2, Tg2, E, sig, CM);
+        const double Eg = readlane_f64(E[0], g), sg = readlane_f64(sig[0], g), cpr = readlane_f64(CM[0], g ? g - 1 : 0);
+        const double cp = g ? cpr : 0.0;
+        const double upm = __shfl_up(m[cdf], 1), upc = __shfl_up(CM[0], 1);
+        const size_t o = (size_t)cdf * sb.nsegp_g + b;
+        if (b < nseg) {
+            sb.abs_cm[o] = __builtin_fmax(cp, Eg + sg * m[cdf]);
+            sb.tab_e[o] = e[cdf];
+            sb.tab_m[o] = lane ? upm : 0.0;            // ABSOLUTE layout: tab_m holds mp (the running maximum BEFORE the segment)
+            sb.abs_dexp[o] = dexp_of(sc[cdf]);
+        }
+        if (g == 0 && lane < PG_ABS_WAVES) {
+            double* gr = sb.abs_grp + (size_t)cdf * 4 * PG_ABS_WAVES;
+            gr[lane] = E[0];
+            gr[PG_ABS_WAVES + lane] = sig[0];
+            gr[2 * PG_ABS_WAVES + lane] = lane ? upc : 0.0;
+            if (lane == 0) gr[3 * PG_ABS_WAVES] = S;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Search window of a workgroup (256 threads) in LDS
 // ------------------------------------------------------------------------------------------
-template <bool LOCAL>
+// how the window of a workgroup is filled
+#define PG_WM_GROUPS 0   // group records of k_groups + a top scan by one wave: any size, any number of ranks
+#define PG_WM_LOCAL 1    // every workgroup scans all groups itself from the raw partials (single device, <= 1024 segments)
+#define PG_WM_ABS 2      // absolute records of k_groups_abs, one round of loads (single device, <= 1024 segments)
+template <int LOCAL>
 struct WinSmemT {
     double cm[PG_WIN_SEG];   // running maximum of the CDF at the end of every window segment, +inf beyond the window
     union {
@@ -156,7 +222,7 @@ struct WinSmemT {
     } u;
     short dexp[PG_WIN_SEG];   // log2 of the segment scales
     double gE[PG_WIN_GRP], gS[PG_WIN_GRP], gCP[PG_WIN_GRP];   // window groups: E, sigma, CM of the group before
-    double topCM[LOCAL ? 1 : PG_MAX_GRP], topE[LOCAL ? 1 : PG_MAX_GRP], topS[LOCAL ? 1 : PG_MAX_GRP];
+    double topCM[LOCAL ? 1 : PG_MAX_GRP], topE[LOCAL ? 1 : PG_MAX_GRP], topS[LOCAL ? 1 : PG_MAX_GRP];   // PG_WM_GROUPS only
     double grK[PG_WIN_GRP], grT[PG_WIN_GRP];   // LOCAL: group records found by the waves
     int cand_b[PG_NCAND];
     double cand_cy[PG_NCAND];
@@ -172,12 +238,40 @@ struct WinSmemT {
 // otherwise: the group records of k_groups give the top level; the window holds the groups [g_lo, g_hi] (at most 16).
 // Out: S, first global segment of the window, number of window segments; returns false when the thresholds span more than the
 // window can hold (the caller then searches slot by slot through global memory).
-template <bool LOCAL>
+template <int LOCAL>
 __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs& sb, int cdf, int nseg, double U_first, double U_last,
                                             double& S, int& win_b0, int& nwin) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n1 = (nseg + PG_GRP - 1) / PG_GRP;
-    if constexpr (LOCAL) {
+    if constexpr (LOCAL == PG_WM_ABS) {
+        // everything was finished by k_groups_abs: one round of independent, coalesced loads
+        const size_t o = (size_t)cdf * sb.nsegp_g;
+        const double* __restrict__ gr = sb.abs_grp + (size_t)cdf * 4 * PG_ABS_WAVES;
+        S = gr[3 * PG_ABS_WAVES];
+#pragma unroll
+        for (int i = 0; i < PG_WIN_SEG / PG_BLK; ++i) {
+            const int wb = i * PG_BLK + tid;
+            const bool in = wb < nseg;
+            sm.cm[wb] = in ? sb.abs_cm[o + wb] : __builtin_inf();
+            sm.u.tab.e[wb] = in ? sb.tab_e[o + wb] : 0.0;
+            sm.u.tab.mp[wb] = in ? sb.tab_m[o + wb] : 0.0;
+            sm.dexp[wb] = (short)(in ? sb.abs_dexp[o + wb] : PG_DEXP_ZERO);
+        }
+        if (tid < PG_WIN_GRP) {
+            sm.gE[tid] = gr[tid];
+            sm.gS[tid] = gr[PG_ABS_WAVES + tid];
+            sm.gCP[tid] = gr[2 * PG_ABS_WAVES + tid];
+        }
+        __syncthreads();
+        win_b0 = 0;
+        nwin = nseg;
+        (void)U_first;
+        (void)U_last;
+        (void)n1;
+        (void)lane;
+        (void)wave;
+        return true;
+    } else if constexpr (LOCAL == PG_WM_LOCAL) {
         double mreg[PG_WIN_GRP / 4];
 #pragma unroll
         for (int e4 = 0; e4 < PG_WIN_GRP / 4; ++e4) {
@@ -399,7 +493,7 @@ __device__ __forceinline__ double slot_U(double u1, int64_t i, int N, double inv
 // slot slot_of(tid, j), a GLOBAL particle index.  md.p0 / md.Ng / md.nseg_g place the device's shard in the global
 // particle range (single device: 0 / N / nseg).  Leaves LDS free for reuse after a trailing barrier of the caller.
 // ------------------------------------------------------------------------------------------
-template <bool LOCAL>
+template <int LOCAL>
 __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOCAL>& sm, double u1, const ScanBufs& sb, const Peers& pr,
                                                 int seg, int (&a)[PG_PPT]) {
     const int tid = threadIdx.x;
@@ -529,7 +623,7 @@ __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOC
             }
         }
     } else if (valid && !covered) {
-        if constexpr (!LOCAL) {
+        if constexpr (LOCAL == PG_WM_GROUPS) {
 #pragma unroll
             for (int j = 0; j < PG_PPT; ++j) a[j] = slot_search_global(sm, sb, pr, 0, nseg, N, tau[j]);
         }
@@ -537,7 +631,7 @@ __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOC
 }
 
 // Search + the bookkeeping every caller needs: conditioned slot, slot-major -> particle-major through LDS, ancestor trace.
-template <bool LOCAL>
+template <int LOCAL>
 __device__ __forceinline__ void resample_slots(const DevModel& md, WinSmemT<LOCAL>& sm, double u1, const ScanBufs& sb, const Peers& pr, int seg,
                                                int32_t* __restrict__ anc_out, int (&anc_pm)[PG_PPT], int ref_idx /* < 0: none */) {
     const int tid = threadIdx.x;
@@ -568,13 +662,16 @@ __device__ __forceinline__ void resample_slots(const DevModel& md, WinSmemT<LOCA
 // segment -- lw2_i = (la_s[i] + logw_{s-1}[i]) + h_s[i] with logw_{s-1}[i] = ln_{s-1}[i] - la_{s-1}[a_{s-1}[i]] (0 for s = 1),
 // the same expressions, the segment's stored reference k, the same fixed-point numerators and an exact integer cumsum --
 // and counts against it.  Bit-identical to a stored version.
-struct AncIn {
-    int64_t row_s;      // offset of row s in la/h/ln buffers (s * np_l)
-    int64_t row_p;      // offset of row s-1, or -1 for s = 1
-    int64_t anc_row_p;  // offset of the ancestors of step s-1 in anc_trace ((s-2) * N_l)
+struct AncIn {          // row pointers of every rank (this device's own rows or xGMI peer mappings), filled in by the host per launch
+    const double* la_s[PG_MAX_RANKS];    // row s of la: log p(y_s | aux_s)
+    const double* h_s[PG_MAX_RANKS];     // row s of h:  log N(ref_s; aux_s, S)
+    const double* ln_p[PG_MAX_RANKS];    // row s-1 of ln (has_prev)
+    const double* la_p[PG_MAX_RANKS];    // row s-1 of la (has_prev)
+    const int32_t* anc_p[PG_MAX_RANKS];  // ancestors of step s-1 = row s-2 of the ancestor trace (has_prev)
+    int32_t has_prev;                    // 0 for s = 1: logw_0 = 0
 };
 
-template <bool LOCAL>
+template <int LOCAL>
 __device__ __forceinline__ int cdf_count_wg(WinSmemT<LOCAL>& sm, const ScanBufs& sb, const Peers& pr, int cdf, int nseg, int N, double U,
                                             const uint64_t* __restrict__ cbuf, const uint64_t* const* cb_ranks, const AncIn* rebuild) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -600,8 +697,10 @@ __device__ __forceinline__ int cdf_count_wg(WinSmemT<LOCAL>& sm, const ScanBufs&
         const int r = pr.world > 1 ? b / pr.nseg_l : 0;
         const int64_t lbase = base - (int64_t)r * pr.Nl;   // local particle index of the segment's first particle on rank r
         const double kref = sb.segk[partial_at(sb, cdf, b)];
-        const double* __restrict__ la_s = pr.la[r] + rebuild->row_s;
-        const double* __restrict__ h_s = pr.h[r] + rebuild->row_s;
+        const double* __restrict__ la_s = rebuild->la_s[r];
+        const double* __restrict__ h_s = rebuild->h_s[r];
+        const double* __restrict__ ln_p = rebuild->ln_p[r];
+        const int32_t* __restrict__ anc_p = rebuild->anc_p[r];
         double arg[PG_PPT], ev[PG_PPT];
 #pragma unroll
         for (int j = 0; j < PG_PPT; ++j) {
@@ -610,10 +709,10 @@ __device__ __forceinline__ int cdf_count_wg(WinSmemT<LOCAL>& sm, const ScanBufs&
             if (i < n) {
                 const int64_t li = lbase + i;
                 double logw = 0.0;
-                if (rebuild->row_p >= 0) {
-                    const int ap = pr.anc[r][rebuild->anc_row_p + li];   // GLOBAL index of the ancestor at step s-1
+                if (rebuild->has_prev) {
+                    const int ap = anc_p[li];   // GLOBAL index of the ancestor at step s-1
                     const int ra = pr.world > 1 ? ap / pr.Nl : 0;
-                    logw = pr.ln[r][rebuild->row_p + li] - pr.la[ra][rebuild->row_p + (ap - (int64_t)ra * pr.Nl)];
+                    logw = ln_p[li] - rebuild->la_p[ra][ap - (int64_t)ra * pr.Nl];
                 }
                 const double l1 = la_s[li] + logw;
                 lw2 = l1 + h_s[li];
@@ -647,9 +746,9 @@ __device__ __forceinline__ int cdf_count_wg(WinSmemT<LOCAL>& sm, const ScanBufs&
 // k_count: one workgroup; what = 0: reference ancestor of pgas_step (CDF 1 against c2) -> hdr->ref_idx,
 //                          what = 1: final index (CDF 0 against c1)                    -> hdr->final_idx
 __global__ __launch_bounds__(PG_BLK) void k_count(int N, int nseg, ScanBufs sb, Peers pr, int what, double u) {
-    __shared__ WinSmemT<false> sm;
+    __shared__ WinSmemT<PG_WM_GROUPS> sm;
     const int cdf = what == 0 ? 1 : 0;
-    const int r = cdf_count_wg<false>(sm, sb, pr, cdf, nseg, N, u, cdf ? sb.c2 : sb.c1, cdf ? pr.c2 : pr.c1, nullptr);
+    const int r = cdf_count_wg<PG_WM_GROUPS>(sm, sb, pr, cdf, nseg, N, u, cdf ? sb.c2 : sb.c1, cdf ? pr.c2 : pr.c1, nullptr);
     if (threadIdx.x == 0) {
         if (what == 0) sb.hdr->ref_idx = r; else sb.hdr->final_idx = r;
     }
@@ -661,12 +760,12 @@ __global__ __launch_bounds__(PG_BLK) void k_count(int N, int nseg, ScanBufs sb, 
 template <int NX>
 __global__ __launch_bounds__(PG_BLK) void k_back(DevModel md, int t, double u1, const double* __restrict__ x_cur, ScanBufs sb, Peers pr,
                                                   int32_t* __restrict__ anc_out, double* __restrict__ logw_out) {
-    __shared__ WinSmemT<false> sm;
+    __shared__ WinSmemT<PG_WM_GROUPS> sm;
     const int seg = blockIdx.x, tid = threadIdx.x;
     double xv[PG_PPT][NX];
     load_particles<NX>(md, x_cur, seg, xv);
     int anc[PG_PPT];
-    resample_slots<false>(md, sm, u1, sb, pr, seg, anc_out, anc, sb.hdr->ref_idx);
+    resample_slots<PG_WM_GROUPS>(md, sm, u1, sb, pr, seg, anc_out, anc, sb.hdr->ref_idx);
     const double* __restrict__ yt = md.y + (size_t)t * md.ny;
 #pragma unroll
     for (int r = 0; r < PG_PPT; ++r) {
@@ -685,10 +784,10 @@ __global__ __launch_bounds__(PG_BLK) void k_back_corrected(DevModel md, TransPar
                                                             const double* __restrict__ aux, const double* __restrict__ ref_t, ScanBufs sb, Peers pr,
                                                             int32_t* __restrict__ anc_out, double* __restrict__ x_new,
                                                             double* __restrict__ logw_out) {
-    __shared__ WinSmemT<false> sm;
+    __shared__ WinSmemT<PG_WM_GROUPS> sm;
     const int seg = blockIdx.x, tid = threadIdx.x;
     int anc[PG_PPT];
-    resample_slots<false>(md, sm, u1, sb, pr, seg, anc_out, anc, sb.hdr->ref_idx);
+    resample_slots<PG_WM_GROUPS>(md, sm, u1, sb, pr, seg, anc_out, anc, sb.hdr->ref_idx);
     const double* __restrict__ yt = md.y + (size_t)t * md.ny;
     double z0[PG_PPT], z1[PG_PPT];
     {
@@ -721,9 +820,9 @@ __global__ __launch_bounds__(PG_BLK) void k_back_corrected(DevModel md, TransPar
 // systematic_SISR (src/Filtering.py:6-37) on a weight vector whose segment scans (k_segscan) and group records (k_groups) are in sb
 __global__ __launch_bounds__(PG_BLK) void k_systematic(DevModel md, double u, const double* __restrict__ u_dev, ScanBufs sb, Peers pr,
                                                       int32_t* __restrict__ idx_out) {
-    __shared__ WinSmemT<false> sm;
+    __shared__ WinSmemT<PG_WM_GROUPS> sm;
     int anc[PG_PPT];
-    resample_slots<false>(md, sm, u_dev ? u_dev[0] : u, sb, pr, blockIdx.x, idx_out, anc, -1);
+    resample_slots<PG_WM_GROUPS>(md, sm, u_dev ? u_dev[0] : u, sb, pr, blockIdx.x, idx_out, anc, -1);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -747,15 +846,15 @@ struct StepArgs {
     const double* la_t;      // (np) row t of la_buf, this device
     const double* h_t;       // (np) row t of h_buf
     const double* ln_prev;   // (np) row t-1 of ln_buf
-    int64_t row_prev;        // offset of row t-1 in la/h/ln buffers (peer reads of log p(y_{t-1} | aux_{t-1}) of remote ancestors)
-    AncIn anc_in;            // rows the ancestor workgroup rebuilds from (s = t-1)
+    AncIn anc_in;            // rows of step s = t-1 on every rank: the ancestor workgroup rebuilds its segment from them, and la_s is where
+                             // every workgroup reads log p(y_{t-1} | aux_{t-1}) of its (possibly remote) ancestors
     int32_t* anc_out;        // (N) ancestors of step t-1
     double* logw_out;        // optional (N) logw_{t-1}
 };
 
 // Out-of-line copy for the path that practically never runs (the hand-off word of the ancestor workgroup did not arrive within
 // the spin budget): keeps the second instance of the count out of k_step's instruction stream.
-template <bool LOCAL>
+template <int LOCAL>
 __device__ PG_COLD_ATTR int cdf_count_wg_cold(WinSmemT<LOCAL>& sm, const ScanBufs& sb, const Peers& pr, int nseg, int N, double U, const AncIn& in) {
     return cdf_count_wg<LOCAL>(sm, sb, pr, 1, nseg, N, U, nullptr, nullptr, &in);
 }
@@ -766,7 +865,7 @@ __device__ PG_COLD_ATTR int cdf_count_wg_cold(WinSmemT<LOCAL>& sm, const ScanBuf
 #ifndef PG_STEP_OCC
 #define PG_STEP_OCC 4   // waves per SIMD k_step is compiled for: 4 -> 108 VGPRs and no scratch; 5 (the LDS limit, 5 x 31 KB) -> 96 VGPRs + 36 B/lane of scratch = 15 MB more HBM traffic per launch at the same speed
 #endif
-template <bool LOCAL, bool TAIL = false>
+template <int LOCAL, bool TAIL = false>
 __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepArgs ar, ScanBufs sb_prev, ScanBufs sb_next, Peers pr) {
     __shared__ WinSmemT<LOCAL> sm;
     const int tid = threadIdx.x;
@@ -833,7 +932,7 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
                 // log p(y_{t-1} | aux_{t-1}) of the ancestor: this device's row, or the owning peer's (src/PGAS.py:146)
                 const int an = sm.u.a[r * PG_BLK + tid];
                 const int ra = pr.world > 1 ? an / pr.Nl : 0;
-                lwp[r] = lnv[r] - pr.la[ra][ar.row_prev + (an - (int64_t)ra * pr.Nl)];
+                lwp[r] = lnv[r] - ar.anc_in.la_s[ra][an - (int64_t)ra * pr.Nl];
             }
         }
         PG_STAMP(5);

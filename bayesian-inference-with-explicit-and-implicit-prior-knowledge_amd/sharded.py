@@ -43,6 +43,12 @@ class _Shard:
         self.segs_w = [eng.dev_tensor(self.ptrs[11 + i], (w,), torch.int64) for i in range(2)]
         self.segm_g = [eng.dev_tensor(self.ptrs[13 + i], (world * w,), torch.float64) for i in range(2)]
         self.segs_g = [eng.dev_tensor(self.ptrs[15 + i], (world * w,), torch.int64) for i in range(2)]
+        # the seven buffers peers read (two segment cumsums, la, h, ln, x, anc), block by block: the traces are row blocks of <= 1 GiB
+        self.nblk = [eng.shard_layout(k)[0] for k in range(7)]
+
+    def blocks(self):
+        """[(which, blk, device pointer)] of every peer-visible block of this rank."""
+        return [(k, b, self.eng.shard_block(k, b)[0]) for k in range(7) for b in range(self.nblk[k])]
 
 
 class LocalGroup:
@@ -52,7 +58,8 @@ class LocalGroup:
         self.shards = shards
         for s in shards:
             for peer, o in enumerate(shards):
-                s.eng.shard_set_peer(peer, o.ptrs[:7])
+                for which, blk, ptr in o.blocks():
+                    s.eng.shard_set_peer_block(peer, which, blk, ptr)
 
     def all_gather(self, parity):
         w = 2 * self.shards[0].nsegp
@@ -94,36 +101,37 @@ class DistGroup:
         self.dist, self.group, self.shards = dist, group, [shard]
         self.library_loop = True
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        # The HIP 7.0 runtime PyTorch 2.10+rocm7.0 bundles hangs in hipIpcOpenMemHandle for allocations of 2 GiB and more (measured:
-        # 2047 MiB opens in 0.4 ms, 2048 MiB never returns; ROCm 7.2's opens 34 GB in 0.3 ms).  Refuse on every rank rather than hang:
-        # the cure is the system runtime under the same process (LD_PRELOAD, what bench.py does for its multi-rank runs).
-        def ipc_hazard():
-            ver = int(shard.eng.lib.pgas_hip_runtime_version())
-            biggest = 8 * shard.T * shard.Nl * max(shard.eng.nx, 1)   # x_trace; la / h / ln rows are 8 T N_l bytes each
-            if world > 1 and 0 <= ver < 70200000 and biggest >= (1 << 31):
-                raise PgasError(f"the HIP runtime in this process (version {ver}) hangs in hipIpcOpenMemHandle on allocations >= 2 GiB and the "
-                                f"state trace of this shard has {biggest / 2**30:.1f} GiB: start the process with "
-                                "LD_PRELOAD=/opt/rocm/lib/libamdhip64.so:/opt/rocm/lib/libhsa-runtime64.so (ROCm >= 7.2)")
-
-        agree_on(dist, group, "HIP IPC of buffers above 2 GiB", ipc_hazard)
-        handles = [shard.eng.ipc_export(k) for k in range(7)]
-        everyone = [None] * world
-        dist.all_gather_object(everyone, handles, group=group)
         self.backend = dist.get_backend(group)
 
         def agreed(step, fn):
             agree_on(dist, group, step, fn)
 
+        # Every peer-visible block crosses the process boundary as one HIP IPC handle.  The blocks are at most 1 GiB (pgas_shard_setup):
+        # the HIP 7.0 runtime PyTorch 2.10+rocm7.0 bundles never returns from hipIpcOpenMemHandle for an allocation of 2 GiB or more
+        # (2047 MiB opens in 0.4 ms), and pgas_ipc_export refuses such a block instead of letting a peer hang on it.
+        handles = []
+        agreed("export the IPC handles", lambda: handles.extend((k, b, shard.eng.ipc_export(k, b)) for k, b, _ in shard.blocks()))
+        everyone = [None] * world
+        dist.all_gather_object(everyone, handles, group=group)
+
         def open_peers():
             for peer, hs in enumerate(everyone):
                 if peer == rank:
-                    shard.eng.shard_set_peer(peer, shard.ptrs[:7])
+                    for which, blk, ptr in shard.blocks():
+                        shard.eng.shard_set_peer_block(peer, which, blk, ptr)
                 else:
-                    shard.eng.shard_set_peer(peer, [shard.eng.ipc_open(h) for h in hs])
+                    for which, blk, h in hs:
+                        shard.eng.shard_set_peer_block(peer, which, blk, shard.eng.ipc_open(h))
 
         agreed("open the peers' IPC handles", open_peers)
         if self.backend == "nccl":
-            ident = [shard.eng.shard_unique_id() if rank == 0 else None]
+            ident = [None]
+
+            def make_id():
+                if rank == 0:
+                    ident[0] = shard.eng.shard_unique_id()
+
+            agreed("RCCL unique id", make_id)
             dist.broadcast_object_list(ident, src=0, group=group)
             agreed("RCCL communicator", lambda: shard.eng.shard_comm_init(ident[0]))
         else:
@@ -191,17 +199,24 @@ def sharded_sweep(group, seed, ref, coeff_mat, error_cov, propagate_chunk=0):
     return trajs if len(trajs) > 1 else trajs[0]
 
 
-def make_local_group(world, N_global, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=None):
+def _shard_engine(Nl, args, device, trace_block_bytes):
+    eng = Engine(Nl, *args, device=device)
+    if trace_block_bytes:   # test knob (PGAS_OPT_TRACE_BLOCK_BYTES): block boundaries inside short sweeps; default = 1 GiB blocks
+        eng.set_option(12, int(trace_block_bytes))
+    return eng
+
+
+def make_local_group(world, N_global, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=None, trace_block_bytes=None):
     Nl = shard_layout(N_global, world)
-    shards = [_Shard(Engine(Nl, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=device), r, world)
-              for r in range(world)]
+    args = (observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn)
+    shards = [_Shard(_shard_engine(Nl, args, device, trace_block_bytes), r, world) for r in range(world)]
     return LocalGroup(shards)
 
 
-def make_dist_group(N_global, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=None, group=None):
+def make_dist_group(N_global, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=None, group=None, trace_block_bytes=None):
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     Nl = shard_layout(N_global, world)
-    shard = _Shard(Engine(Nl, observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn, device=device), rank, world)
+    shard = _Shard(_shard_engine(Nl, (observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn), device, trace_block_bytes), rank, world)
     return DistGroup(shard, group)

@@ -209,30 +209,66 @@ def respawn_under_torchrun(args):
     raise SystemExit(subprocess.call(cmd))
 
 
-SYSTEM_HIP = ("/opt/rocm/lib/libamdhip64.so", "/opt/rocm/lib/libhsa-runtime64.so")
+def verify_last_sweep(torch, eng, ref, traj, owns_conditioned, chase):
+    """What the timed region produced must be a conditional-SMC sweep, not just kernels that ran: the trajectory is finite, the final
+    log-weights are finite, the conditioned particle followed the reference at every time (src/PGAS.py:194,214), and (chase=True:
+    unsharded contexts, whose traces this process can index) the trajectory is a path through the state trace along the recorded
+    ancestors (src/Filtering.py:40-55), chased here with plain torch indexing from the final index.  Returns a list of failures."""
+    bad = []
+    T, nx = traj.shape
+    if not bool(torch.isfinite(traj).all()):
+        bad.append("trajectory has non-finite entries")
+    px = eng.traces_blocks(eng.TRACE_X, (eng.N, nx), torch.float64)
+    pa = eng.traces_blocks(eng.TRACE_ANC, (eng.N,), torch.int32)
+    if owns_conditioned:
+        t0 = 0
+        for blk in px:
+            if not torch.equal(blk[:, -1, :], ref[t0:t0 + blk.shape[0]]):
+                bad.append(f"conditioned particle left the reference trajectory in rows {t0}..{t0 + blk.shape[0] - 1}")
+            t0 += blk.shape[0]
+    _, _, lw, _ = eng.traces(copy_blocks=False)
+    if not bool(torch.isfinite(lw).all()):
+        bad.append("final log-weights are not finite")
+    if chase:
+        rx, ra = px[0].shape[0], pa[0].shape[0]
+        b = torch.tensor([eng.last_final_index()], device=traj.device, dtype=torch.int64)
+        ok = torch.ones((), dtype=torch.bool, device=traj.device)
+        for t in range(T - 1, -1, -1):
+            ok = ok & (px[t // rx][t % rx].index_select(0, b)[0] == traj[t]).all()
+            if t:
+                b = pa[(t - 1) // ra][(t - 1) % ra].index_select(0, b).to(torch.int64)
+        if not bool(ok):
+            bad.append("the trajectory is not the ancestral path of the final index through the traces")
+    return bad
 
 
-def system_hip_env(environ, mode, exists=os.path.exists):
-    """The environment a multi-rank run restarts itself with (system ROCm runtime preloaded), or None when no restart is due:
-    single-rank runs, a restart already done (PGAS_SYSTEM_HIP), PGAS_NO_PRELOAD set, or no system runtime on this machine."""
-    multi = int(environ.get("WORLD_SIZE", "1")) > 1 or ("WORLD_SIZE" in environ and mode == "sharded")
-    if not multi or environ.get("PGAS_SYSTEM_HIP") or environ.get("PGAS_NO_PRELOAD") or not all(exists(p) for p in SYSTEM_HIP):
-        return None
-    env = dict(environ)
-    env["PGAS_SYSTEM_HIP"] = "1"
-    env["LD_PRELOAD"] = ":".join(list(SYSTEM_HIP) + [p for p in env.get("LD_PRELOAD", "").split(":") if p and p not in SYSTEM_HIP])
-    return env
-
-
-def use_system_hip_runtime(args):
-    """Multi-rank runs map their peers' trace buffers (tens of GB each) with hipIpcOpenMemHandle, and the HIP 7.0 runtime bundled with
-    PyTorch 2.10+rocm7.0 hangs in that call for allocations >= 2 GiB (tools/ipc_probe.py).  ROCm 7.2's runtime does
-    not: restart this rank with it preloaded -- an exec BEFORE anything has touched the GPU (torch is not even imported yet)."""
-    env = system_hip_env(os.environ, args.mode)
-    if env is None:
-        return
-    sys.stderr.flush()
-    os.execve(sys.executable, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env)
+def sharded_self_check(torch, dist, pgas_amd, experiments, sharded, local_rank, rank, world):
+    """Before anything is timed in sharded mode: a small sharded sweep (8192 particles per rank, T = 12: remote ancestors, the RCCL
+    all-gather, IPC peer reads, the cross-rank ancestor chase) against the SAME sweep on an unsharded context on every rank; the
+    trajectories must be bit-identical on every rank.  Returns None or the failure text (identical on every rank)."""
+    Ns, Ts = 8192, 12
+    pbs = experiments.smo_pgas(T=Ts)
+    A, S = experiments.initial_params(pbs)
+    dev = f"cuda:{local_rank}"
+    err = None
+    try:
+        g = sharded.make_dist_group(Ns * world, pbs.observations, pbs.inputs, pbs.init_state_mean, pbs.init_state_cov, pbs.likelihood_fcn, pbs.basis_fcn, device=dev)
+        tr = sharded.sharded_sweep(g, 4242, pbs.X_true, A, S).clone()
+        one = pgas_amd.condSequentialMonteCarlo(Ns * world, pbs.observations, pbs.inputs, pbs.init_state_mean, pbs.init_state_cov, pbs.likelihood_fcn,
+                                                pbs.basis_fcn, device=dev)
+        tu = one(4242, pbs.X_true, A, S)
+        torch.cuda.synchronize()
+        if not torch.equal(tr, tu):
+            err = f"rank {rank}: sharded trajectory differs from the unsharded one in {int((tr != tu).any(dim=1).sum())} of {Ts} rows"
+        g.barrier()
+        g.shards[0].eng.close()
+        one.engine.close()
+    except Exception as e:   # noqa: BLE001 -- agreed on below
+        err = f"rank {rank}: {type(e).__name__}: {e}"
+    errs = [None] * world
+    dist.all_gather_object(errs, err)
+    bad = [e for e in errs if e]
+    return "; ".join(bad) if bad else None
 
 
 def main():
@@ -262,7 +298,6 @@ def main():
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args)
-    use_system_hip_runtime(args)
 
     import torch
     import torch.distributed as dist
@@ -331,27 +366,33 @@ def main():
             print(f"[rehearse rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     mark("model and parameters ready")
-    grp, shard_fallback = None, None
+    grp = None
+    self_check = None
     if sharded_mode:
         from pgas_amd import sharded
 
         # every rank must use the same (A, S): take rank 0's
         dist.broadcast(A, src=0)
         dist.broadcast(S, src=0)
+        # A sharded run that cannot be set up, or whose small self-check disagrees with the unsharded sweep, ENDS here with a non-zero exit
+        # on every rank: independent chains measured under the sharded metric would put a wrong point into a scaling table.
+        # (`--mode replicas` measures independent chains on purpose.)
+        if not os.environ.get("PGAS_BENCH_NO_SELF_CHECK"):
+            failed = sharded_self_check(torch, dist, pgas_amd, experiments, sharded, local_rank, rank, world)
+            if failed:
+                if rank == 0:
+                    print(f"bench.py: the particle-sharded sweep failed its self-check against the unsharded sweep: {failed}", file=sys.stderr, flush=True)
+                raise SystemExit(3)
+            self_check = f"sharded sweep of {8192 * world} particles, T=12, bit-identical to the unsharded sweep on all {world} ranks (checked in this run, before the timed region)"
+            mark("self-check passed")
         try:
             grp = sharded.make_dist_group(N * world, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn,
                                           pb.basis_fcn, device=f"cuda:{local_rank}")
-            eng = grp.shards[0].eng
-        except sharded.PgasError as e:
-            # make_dist_group raises on EVERY rank when any rank failed (IPC mapping, RCCL communicator).  Measure independent chains
-            # instead of nothing, and say so in the line: config.partition / config.fallback_reason.
-            shard_fallback = str(e)
+        except sharded.PgasError as e:   # raised on EVERY rank when any rank failed (IPC mapping, RCCL communicator)
             if rank == 0:
-                print(f"bench.py: sharded setup failed, falling back to independent chains: {e}", file=sys.stderr, flush=True)
-            grp, sharded_mode, mode = None, False, "replicas"
-            seed = 12345678 + rank
-            wl_name = "SingleMassOscillator PGAS sweep, nx=2, M=41 Hilbert basis (BASELINE.json configs[1])"
-            eng = pg.cSMC.engine
+                print(f"bench.py: setup of the particle-sharded sweep failed: {e}", file=sys.stderr, flush=True)
+            raise SystemExit(3)
+        eng = grp.shards[0].eng
     else:
         eng = pg.cSMC.engine
     if args.chunk >= 0:
@@ -371,9 +412,8 @@ def main():
 
     def one_sweep(sd):
         if grp is not None:
-            sharded.sharded_sweep(grp, sd, ref, A, S)
-        else:
-            pg.cSMC(sd, ref, A, S)
+            return sharded.sharded_sweep(grp, sd, ref, A, S)
+        return pg.cSMC(sd, ref, A, S)
 
     mark("sharded group ready" if grp is not None else "engine ready")
     for w in range(args.warmup):
@@ -389,7 +429,7 @@ def main():
         # launch of every sweep would cost ~8 % of the headline value; one sweep of K gives 2 x (T-1) samples inside the timed region.
         timed_sweep = not args.no_profile and (k == args.steps - 1 or prof_all)
         eng.set_profiling((-1 if stride == 1 else stride) if timed_sweep else 0)
-        one_sweep(seed + k)
+        traj_last = one_sweep(seed + k)
         if timed_sweep:
             n, ms, pn, pm = eng.profile()   # synchronises this sweep
             prof_n += n
@@ -403,6 +443,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    # ---- what was timed must be a sweep: checked on the last timed sweep's traces, after the clock has stopped
+    failures = verify_last_sweep(torch, eng, ref, traj_last.reshape(T, -1), owns_conditioned=(not sharded_mode) or rank == world - 1, chase=not sharded_mode)
+    if sharded_mode:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, (failures, traj_last.cpu().numpy().tobytes()))
+        failures = [f"rank {r}: {m}" for r, (fl, _) in enumerate(everyone) for m in fl]
+        if any(tb != everyone[0][1] for _, tb in everyone):
+            failures.append("the ranks disagree on the sampled trajectory")
+    if failures:
+        if rank == 0:
+            print("bench.py: the timed sweeps are INVALID: " + "; ".join(failures), file=sys.stderr, flush=True)
+        raise SystemExit(4)
+    verified = ("last timed sweep checked after the timed region: trajectory and final log-weights finite, conditioned particle == reference at every t, "
+                + ("every rank sampled the same trajectory" if sharded_mode else "trajectory == ancestral path of the final index through the traces"))
+
     units = N * (T - 1) * args.steps * world
     out = {
         "metric": "particle-steps/sec (N x (T-1) / wall), " + {"smo": "SingleMassOscillator", "vehicle": "Vehicle", "emps": "EMPS"}[args.workload] + " PGAS conditional-SMC sweep",
@@ -413,10 +468,9 @@ def main():
             "workload": f"{wl_name}, N={N} particles/GPU" + (f" ({N * world} in all)" if sharded_mode else "") + f", T={T}, fp64",
             "particles_per_gpu": N, "particles_total": N * world if sharded_mode else N, "T": T,
             "partition": "particle-sharded" if sharded_mode else ("single GPU" if world == 1 else "replicas"),
-            **({"hip_runtime": "system ROCm runtime preloaded (" + ":".join(SYSTEM_HIP) + "): the one bundled with PyTorch hangs in hipIpcOpenMemHandle above 2 GiB"}
-               if os.environ.get("PGAS_SYSTEM_HIP") else {}),
-            **({"fallback_reason": "the particle-sharded sweep was requested but its setup failed; independent chains were measured instead: " + shard_fallback}
-               if shard_fallback else {}),
+            "hip_runtime_version": int(eng.lib.pgas_hip_runtime_version()),
+            "verified": verified,
+            **({"self_check": self_check} if self_check else {}),
             "parallelism": "1 GPU" if world == 1 and not sharded_mode else (
                 f"one sweep of {N * world} particles sharded over {world} GPUs (one process per GPU): per time step one RCCL all-gather of the "
                 f"segment partials + xGMI peer reads of remote ancestors' rows; per-GPU work is fixed as GPUs are added (weak scaling)"
@@ -444,7 +498,7 @@ def main():
             p_us = 1e3 * prop_ms / max(prop_n, 1)
             p_steps = max(info["chunk"], 1)
             p_us_step = p_us / p_steps
-            kname_step = {"local": "k_step<LOCAL>", "tail": "k_step<TAIL>", "k_groups": "k_step (+ k_groups launch)"}[info["groups"]]
+            kname_step = {"local": "k_step<LOCAL>", "tail": "k_step<TAIL>", "k_groups": "k_step (+ k_groups launch)", "abs": "k_step<ABS> (+ k_groups_abs launch)"}[info["groups"]]
             nxv, Dv = pb.nx, len(pb.basis_fcn.sel)
             kname_prop = f"k_propagate<{nxv},{Dv},{info['JP']},{info['P']}>"
             per_launch = ALG_BYTES_PER_PARTICLE_STEP * N

@@ -112,8 +112,20 @@ int pgas_step(pgas_ctx* ctx, int32_t t, uint64_t seed, const double* logw_dev, c
 int pgas_sweep(pgas_ctx* ctx, uint64_t seed, const double* ref_dev, double* traj_dev, void* stream);
 
 /* Device pointers of the traces of the last sweep: x_trace (T,N,nx), anc_trace (T-1,N) int32,
- * logw_last (N) = log_weights_trace[T-1], logw_trace (T,N) or NULL.  Valid until the next sweep. */
+ * logw_last (N) = log_weights_trace[T-1], logw_trace (T,N) or NULL.  Valid until the next sweep.
+ * x_trace / anc_trace are single arrays on an unsharded context (state_trace / ancestor_trace of src/PGAS.py:160-164).  A sharded
+ * context (and any context after PGAS_OPT_TRACE_BLOCK_BYTES) keeps them as ROW BLOCKS -- consecutive time rows in allocations of at
+ * most 1 GiB, so that each can cross process boundaries as one HIP IPC handle -- and refuses x_trace / anc_trace here (PGAS_E_STATE):
+ * pgas_trace_layout gives the blocking, pgas_trace_row the device pointer of one time row. */
 int pgas_get_traces(pgas_ctx* ctx, double** x_trace, int32_t** anc_trace, double** logw_last, double** logw_trace);
+#define PGAS_TRACE_X 0    /* T rows of (N, nx) f64: state_trace[t] */
+#define PGAS_TRACE_LA 1   /* T rows of nseg*1024 f64: log p(y_t | aux_t)      (hand-off rows between the two pipelines) */
+#define PGAS_TRACE_H 2    /* T rows: log N(ref_t; aux_t, S) */
+#define PGAS_TRACE_LN 3   /* T rows: log p(y_t | x_t) */
+#define PGAS_TRACE_ANC 4  /* T-1 rows of N int32: ancestor_trace[t] */
+/* info4 = {rows, rows per block (a power of two; = rows when the trace is one array), blocks, bytes per row} */
+int pgas_trace_layout(pgas_ctx* ctx, int32_t kind, int64_t* info4);
+int pgas_trace_row(pgas_ctx* ctx, int32_t kind, int32_t t, void** row_dev);
 
 /* Index drawn by the last sweep at src/PGAS.py:225 (synchronises the stream). */
 int pgas_last_final_index(pgas_ctx* ctx, int64_t* idx, void* stream);
@@ -149,6 +161,7 @@ int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 #define PGAS_OPT_SYRK_SPLITS 10 /* pgas_suffstats: number of row splits of the Z^T Z product (partial slabs summed in split order); 0 = automatic (about two workgroups per CU) */
 #define PGAS_OPT_TAIL_GROUPS 9 /* 1: single device only: the group scans ride in k_step's tail (in-launch hand-off to the workgroup that completes a group) instead of k_groups launches; measured slower, default 0 */
 #define PGAS_OPT_EVENT_STRIDE 8 /* k_propagate launches per event that gates the weight recursion's stream (default 8) */
+#define PGAS_OPT_TRACE_BLOCK_BYTES 12 /* before the first sweep / pgas_shard_setup: keep the traces in row blocks of at most this many bytes (0 = default: one array per trace on an unsharded context, 1 GiB blocks on a shard); small values are a test knob that puts block boundaries inside short sweeps */
 #define PGAS_OPT_MNIW_VALU 6 /* 1: pgas_m_mniw_solve factorises column by column on the VALU instead of in MFMA-blocked panels (test knob) */
 int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
 
@@ -176,7 +189,13 @@ int pgas_reconstruct_trajectory(pgas_ctx* ctx, const double* x_dev, const int32_
 #define PGAS_SHARD_BACKTRACE 6   /* trajectory (traj_dev), every rank computes the same one     */
 int pgas_shard_setup(pgas_ctx* ctx, int32_t rank, int32_t world);
 int pgas_shard_buffers(pgas_ctx* ctx, void** out17, int64_t* sizes3);
-int pgas_shard_set_peer(pgas_ctx* ctx, int32_t peer, const void* const* bufs7);
+/* The seven buffers a rank's peers read -- which = 0, 1: the segment cumsums of the two scan buffers; 2..6: the la, h, ln, x and
+ * ancestor traces -- block by block: pgas_shard_layout -> info2 = {blocks, rows per block}; pgas_shard_block -> this rank's block;
+ * pgas_shard_set_peer_block installs rank `peer`'s block as addressable from this process (every rank, the own one included, must be
+ * installed before the first sweep).  All ranks have the same layout (equal N_local and T). */
+int pgas_shard_layout(pgas_ctx* ctx, int32_t which, int64_t* info2);
+int pgas_shard_block(pgas_ctx* ctx, int32_t which, int32_t blk, void** ptr_dev, int64_t* bytes);
+int pgas_shard_set_peer_block(pgas_ctx* ctx, int32_t peer, int32_t which, int32_t blk, const void* ptr_dev);
 int pgas_shard_run(pgas_ctx* ctx, int32_t phase, int32_t t, int32_t t_aux, uint64_t seed, const double* ref_dev, double* traj_dev,
                    void* stream);
 /* The whole sharded sweep inside the library: pgas_shard_unique_id on one rank (128 bytes, to be broadcast by the host),
@@ -194,12 +213,14 @@ int pgas_shard_set_collective(pgas_ctx* ctx, pgas_allgather_fn fn, void* user);
 int pgas_shard_sweep(pgas_ctx* ctx, uint64_t seed, const double* ref_dev, double* traj_dev, int32_t propagate_chunk, void* stream);
 /* Measurement aid: issue the step's RCCL all-gather `reps` times on `stream` (between sweeps only). */
 int pgas_shard_probe_collective(pgas_ctx* ctx, int32_t reps, void* stream);
-/* Version of the HIP runtime this library is bound to in the running process (hipRuntimeGetVersion: 7.2.x = 702xxxxx), -1 on failure.
- * Why a caller wants to know: the HIP 7.0 runtime bundled with PyTorch 2.10+rocm7.0 HANGS in hipIpcOpenMemHandle for allocations of
- * 2 GiB and more (7.2 opens a 34 GB one in 0.3 ms); pgas_amd.sharded refuses to map such buffers through it. */
+/* Version of the HIP runtime this library is bound to in the running process (hipRuntimeGetVersion: 7.2.x = 702xxxxx), -1 on failure
+ * (recorded by bench.py; the HIP 7.0 runtime bundled with PyTorch 2.10+rocm7.0 never returns from hipIpcOpenMemHandle for an
+ * allocation of 2 GiB or more, which is why a shard's traces are row blocks of at most 1 GiB). */
 int32_t pgas_hip_runtime_version(void);
 
-int pgas_ipc_export(pgas_ctx* ctx, int32_t which, void* handle64);
+/* HIP IPC plumbing for peers in OTHER processes: a 64-byte handle of block `blk` of this rank's buffer `which` (as in
+ * pgas_shard_layout), and the mapping of a peer's handle into this process (xGMI peer access is enabled on first use). */
+int pgas_ipc_export(pgas_ctx* ctx, int32_t which, int32_t blk, void* handle64);
 int pgas_ipc_open(pgas_ctx* ctx, const void* handle64, void** ptr);
 
 /* Test hook: the arithmetic primitives shared with the CPU oracle (include/pgas_detmath.h, include/pgas_canon.h) evaluated ON THE

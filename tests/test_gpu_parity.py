@@ -87,6 +87,10 @@ def test_basis_init_step_bit_exact(name, N):
     ("toy", 1500, {1: 1}),            # PGAS_OPT_PROPAGATE_CHUNK = 1: one k_propagate launch per step
     ("smo", 5000, {8: 3, 11: 2}),     # PGAS_OPT_EVENT_STRIDE = 3, PGAS_OPT_MAX_LEAD = 2: k_propagate at most two event groups ahead of the chain
     ("smo", 5000, {3: 0}),            # PGAS_OPT_OVERLAP = 0: both pipelines on the caller's stream
+    ("smo", 5000, {12: 1 << 18}),     # PGAS_OPT_TRACE_BLOCK_BYTES: traces in row blocks (2 state rows, 4 hand-off rows, 8 ancestor rows per block)
+    ("smo", 70000, {12: 4 << 20, 1: 7}),   # ... with k_propagate chunks of 7 steps that straddle block boundaries (split launches)
+    ("emps", 2048, {12: 1 << 17}),    # ... 3-D basis, 4 state rows per block
+    ("toy", 1500, {12: 16384}),       # ... one row per block
     # N <= 1024: one segment, one group
     ("smo", 1024, {}), ("smo", 777, {}), ("toy", 300, {}), ("toy", 1, {}), ("emps", 500, {}), ("veh", 640, {}), ("veh27", 1000, {}), ("smo", 777, {7: 1}),
 ])
@@ -210,6 +214,41 @@ def test_full_size_properties():
             b = An[t - 1, b]
 
 
+@pytest.mark.parametrize("name,steps", [("smo", (500, 1000, 1500, 1998, 1999)), ("emps", (1200, 1999))])
+def test_full_size_late_time_parity(name, steps):
+    """The regime bench.py times: N = 2^20, T = 2000, weights after hundreds of resampling generations.  Teacher-forced oracle steps
+    late in the sweep (inputs = the device's own previous states and log-weights), the final index (src/PGAS.py:224-225) and the whole
+    back-trace (src/Filtering.py:40-55) chased independently through the device's traces -- all bit for bit."""
+    T, N = 2000, 1 << 20
+    pb = experiments.smo_pgas(T=T) if name == "smo" else experiments.emps_pgas(T=T)
+    A, S = experiments.initial_params(pb)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
+                                             pb.likelihood_fcn, pb.basis_fcn, keep_logw_trace=True)
+    traj = csmc(SEED, pb.X_true, A, S)
+    X, ANC, LW, LT = csmc.engine.traces()
+    assert torch.equal(X[:, -1, :], torch.as_tensor(pb.X_true, device=X.device)), "conditioned particle must follow the reference"
+    assert bool(torch.isfinite(LT).all())
+    cm = canon_model(pb, N)
+    LS, LSinv, cS = cm.chol_parts(S)
+    for t in steps:
+        lwo, xo, ao = cm.step(t, SEED, X[t - 1].cpu().numpy(), LT[t - 1].cpu().numpy(), A, LS, LSinv, cS, pb.X_true[t])
+        _eq(X[t], xo, f"{name}: x_trace[{t}] at N=2^20")
+        _eq(ANC[t - 1], ao, f"{name}: anc_trace[{t - 1}] at N=2^20")
+        _eq(LT[t], lwo, f"{name}: log_weights_trace[{t}] at N=2^20")
+        assert len(np.unique(ao)) < N, "late steps do resample"
+    _eq(LW, LT[T - 1].cpu().numpy(), "logw_last == log_weights_trace[T-1]")
+    b = csmc.engine.last_final_index()
+    assert b == cm.final_index(SEED, LW.cpu().numpy()), "final index"
+    # the ancestral path of that index, chased here element by element (not with the library's kernel)
+    bt = torch.tensor([b], device=X.device, dtype=torch.int64)
+    path = torch.empty_like(traj)
+    for t in range(T - 1, -1, -1):
+        path[t] = X[t].index_select(0, bt)[0]
+        if t:
+            bt = ANC[t - 1].index_select(0, bt).to(torch.int64)
+    assert torch.equal(path, traj), "trajectory != ancestral path of the final index"
+
+
 @pytest.mark.parametrize("name", ["emps", "veh"])
 def test_full_size_properties_m729(name):
     """BASELINE configs[2] / configs[4] at their full size (N = 2^20, M = 729, 3-D basis; T shortened): size-independent properties
@@ -270,8 +309,9 @@ def test_error_reporting():
                                           lambda o, s, i: 0.0, pb.basis_fcn)
 
 
-@pytest.mark.parametrize("name,N,world", [("smo", 4096, 2), ("smo", 8192, 4), ("smo", 65536, 8), ("toy", 2048, 2), ("emps", 2048, 2), ("veh27", 4096, 2)])
-def test_sharded_sweep_bit_exact_and_independent_of_world(name, N, world):
+@pytest.mark.parametrize("name,N,world,blk", [("smo", 4096, 2, None), ("smo", 8192, 4, 1 << 17), ("smo", 65536, 8, None), ("toy", 2048, 2, 8192), ("emps", 2048, 2, None),
+                                               ("veh27", 4096, 2, 1 << 16)])
+def test_sharded_sweep_bit_exact_and_independent_of_world(name, N, world, blk):
     """Particle-sharded sweep (several shards emulated in one process on one device): the trajectory and the traces are the
     single-device / oracle ones bit for bit, whatever the number of shards."""
     from pgas_amd import sharded
@@ -281,7 +321,12 @@ def test_sharded_sweep_bit_exact_and_independent_of_world(name, N, world):
     cm = canon_model(pb, N)
     LS, LSinv, cS = cm.chol_parts(S)
     trajo, Xo, ANCo, lwo = cm.sweep(SEED, pb.X_true, A, LS, LSinv, cS, pb.init_state_mean, np.linalg.cholesky(pb.init_state_cov))
-    grp = sharded.make_local_group(world, N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+    # blk: traces in small row blocks (the default is 1 GiB: one block at these sizes), so that peers' rows, the chunked propagation
+    # and the cross-rank ancestor chase all cross block boundaries
+    grp = sharded.make_local_group(world, N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn,
+                                   trace_block_bytes=blk)
+    if blk:
+        assert grp.shards[0].nblk[5] > 1, "the state trace should span several blocks in this case"
     trajs = sharded.sharded_sweep(grp, SEED, pb.X_true, A, S, propagate_chunk=5)
     Nl = N // world
     for r, (s, tr) in enumerate(zip(grp.shards, trajs)):

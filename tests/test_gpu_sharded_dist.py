@@ -48,8 +48,10 @@ def _worker(rank, world, port, N, q, backend="gloo", one_gpu_per_rank=False):
 
         pb = experiments.smo_pgas(T=12)
         A, S = experiments.initial_params(pb)
+        # traces in row blocks of 128 KiB (default 1 GiB): every peer-visible trace crosses the process boundary as SEVERAL IPC handles
         grp = sharded.make_dist_group(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn,
-                                      device=f"cuda:{dev}")
+                                      device=f"cuda:{dev}", trace_block_bytes=1 << 17)
+        assert grp.shards[0].nblk[5] > 1
         assert grp.library_loop and grp.backend == backend
         traj = sharded.sharded_sweep(grp, 12345678, pb.X_true, A, S, propagate_chunk=4)
         traj = sharded.sharded_sweep(grp, 12345678, pb.X_true, A, S, propagate_chunk=4)   # twice: the end-of-sweep collective orders the reuse

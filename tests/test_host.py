@@ -106,22 +106,3 @@ def test_draw_pred_is_a_scaled_student_t():
     assert np.array_equal(pgas_amd.prior_mniw_drawPred(k, np.array([1.5]), col, row, df), pgas_amd.prior_mniw_drawPred(k, np.array([1.5]), col, row, df))
 
 
-def test_bench_restarts_multi_rank_runs_on_the_system_hip_runtime():
-    """bench.system_hip_env: the restart decision that keeps multi-rank runs off PyTorch's bundled HIP runtime (whose hipIpcOpenMemHandle
-    hangs on allocations >= 2 GiB).  Pure function of the environment: checked here without a GPU."""
-    import importlib.util
-    import os
-
-    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    yes, no = (lambda p: True), (lambda p: False)
-    assert bench.system_hip_env({}, "auto", yes) is None                                   # plain single-GPU run: untouched
-    assert bench.system_hip_env({"WORLD_SIZE": "1"}, "auto", yes) is None                  # one rank under a launcher, unsharded
-    env = bench.system_hip_env({"WORLD_SIZE": "8", "RANK": "3", "LD_PRELOAD": "/x/libfoo.so"}, "auto", yes)
-    assert env["PGAS_SYSTEM_HIP"] == "1" and env["RANK"] == "3"
-    assert env["LD_PRELOAD"].split(":") == list(bench.SYSTEM_HIP) + ["/x/libfoo.so"]       # system runtime first, what was there kept
-    assert bench.system_hip_env({"WORLD_SIZE": "1"}, "sharded", yes) is not None            # one-rank sharded rehearsal goes the same way
-    assert bench.system_hip_env(env, "auto", yes) is None                                  # never twice
-    assert bench.system_hip_env({"WORLD_SIZE": "8", "PGAS_NO_PRELOAD": "1"}, "auto", yes) is None
-    assert bench.system_hip_env({"WORLD_SIZE": "8"}, "auto", no) is None                    # no system runtime on this machine
