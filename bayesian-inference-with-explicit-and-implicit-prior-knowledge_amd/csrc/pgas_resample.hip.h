@@ -248,19 +248,34 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
         const size_t o = (size_t)cdf * sb.nsegp_g;
         const double* __restrict__ gr = sb.abs_grp + (size_t)cdf * 4 * PG_ABS_WAVES;
         S = gr[3 * PG_ABS_WAVES];
+        // all loads first, unconditionally (clamped indices): a guarded load per array and row makes the compiler wait for each in turn
+        constexpr int NR = PG_WIN_SEG / PG_BLK;
+        double vcm[NR], ve[NR], vmp[NR];
+        int vdx[NR];
 #pragma unroll
-        for (int i = 0; i < PG_WIN_SEG / PG_BLK; ++i) {
+        for (int i = 0; i < NR; ++i) {
+            const int wb = i * PG_BLK + tid;
+            const size_t at = o + (wb < nseg ? wb : nseg - 1);
+            vcm[i] = sb.abs_cm[at];
+            ve[i] = sb.tab_e[at];
+            vmp[i] = sb.tab_m[at];
+            vdx[i] = sb.abs_dexp[at];
+        }
+        const int gt = tid < PG_WIN_GRP ? tid : 0;
+        const double g0 = gr[gt], g1 = gr[PG_ABS_WAVES + gt], g2 = gr[2 * PG_ABS_WAVES + gt];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
             const int wb = i * PG_BLK + tid;
             const bool in = wb < nseg;
-            sm.cm[wb] = in ? sb.abs_cm[o + wb] : __builtin_inf();
-            sm.u.tab.e[wb] = in ? sb.tab_e[o + wb] : 0.0;
-            sm.u.tab.mp[wb] = in ? sb.tab_m[o + wb] : 0.0;
-            sm.dexp[wb] = (short)(in ? sb.abs_dexp[o + wb] : PG_DEXP_ZERO);
+            sm.cm[wb] = in ? vcm[i] : __builtin_inf();
+            sm.u.tab.e[wb] = in ? ve[i] : 0.0;
+            sm.u.tab.mp[wb] = in ? vmp[i] : 0.0;
+            sm.dexp[wb] = (short)(in ? vdx[i] : PG_DEXP_ZERO);
         }
         if (tid < PG_WIN_GRP) {
-            sm.gE[tid] = gr[tid];
-            sm.gS[tid] = gr[PG_ABS_WAVES + tid];
-            sm.gCP[tid] = gr[2 * PG_ABS_WAVES + tid];
+            sm.gE[tid] = g0;
+            sm.gS[tid] = g1;
+            sm.gCP[tid] = g2;
         }
         __syncthreads();
         win_b0 = 0;
@@ -363,6 +378,17 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
         nwin = ngw * PG_GRP < nseg - win_b0 ? ngw * PG_GRP : nseg - win_b0;
         if (nwin < 0) nwin = 0;
         const size_t o = (size_t)cdf * sb.nsegp_g;
+        // the records of all (up to sixteen) window groups in one round of loads: clamped indices, no guards around the loads
+        constexpr int NR = PG_WIN_SEG / PG_BLK;
+        double ve[NR], vsc[NR], vm[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int b = win_b0 + ((wave + 4 * i) << 6) + lane;
+            const size_t at = o + (size_t)(b < nseg ? b : nseg - 1);
+            ve[i] = sb.tab_e[at];
+            vsc[i] = sb.tab_sc[at];
+            vm[i] = sb.tab_m[at];
+        }
 #pragma unroll
         for (int i = 0; i < PG_WIN_SEG / PG_BLK; ++i) {
             const int gw = wave + 4 * i, wb = (gw << 6) + lane, g = g_lo + gw, b = win_b0 + wb;
@@ -370,9 +396,9 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
             if (gw < ngw) {   // wave-uniform
                 double e = 0.0, sc = 0.0, m = 0.0;
                 if (b < nseg) {
-                    e = sb.tab_e[o + b];
-                    sc = sb.tab_sc[o + b];
-                    m = sb.tab_m[o + b];
+                    e = ve[i];
+                    sc = vsc[i];
+                    m = vm[i];
                 }
                 const double upm = __shfl_up(m, 1);
                 const double Eg = sm.topE[g], sg = sm.topS[g], cp = g ? sm.topCM[g - 1] : 0.0;
@@ -702,22 +728,44 @@ __device__ __forceinline__ int cdf_count_wg(WinSmemT<LOCAL>& sm, const ScanBufs&
         const double* __restrict__ ln_p = rebuild->ln_p[r];
         const int32_t* __restrict__ anc_p = rebuild->anc_p[r];
         double arg[PG_PPT], ev[PG_PPT];
+        {
+            // loads in rounds, every round issued for the four particles together (clamped indices instead of guards)
+            int64_t li[PG_PPT];
+            double las[PG_PPT], hs[PG_PPT], lnp[PG_PPT], lap[PG_PPT];
+            int apv[PG_PPT];
 #pragma unroll
-        for (int j = 0; j < PG_PPT; ++j) {
-            const int i = PG_PPT * tid + j;
-            double lw2 = -__builtin_inf();
-            if (i < n) {
-                const int64_t li = lbase + i;
-                double logw = 0.0;
-                if (rebuild->has_prev) {
-                    const int ap = anc_p[li];   // GLOBAL index of the ancestor at step s-1
-                    const int ra = pr.world > 1 ? ap / pr.Nl : 0;
-                    logw = ln_p[li] - rebuild->la_p[ra][ap - (int64_t)ra * pr.Nl];
-                }
-                const double l1 = la_s[li] + logw;
-                lw2 = l1 + h_s[li];
+            for (int j = 0; j < PG_PPT; ++j) {
+                const int i = PG_PPT * tid + j;
+                li[j] = lbase + (i < n ? i : n - 1);
+                las[j] = la_s[li[j]];
+                hs[j] = h_s[li[j]];
+                lnp[j] = 0.0;
+                lap[j] = 0.0;
             }
-            arg[j] = pgas_seg_arg(lw2, kref);
+            if (rebuild->has_prev) {   // uniform
+#pragma unroll
+                for (int j = 0; j < PG_PPT; ++j) {
+                    apv[j] = anc_p[li[j]];   // GLOBAL index of the ancestor at step s-1
+                    lnp[j] = ln_p[li[j]];
+                }
+                const double* rowp[PG_PPT];
+                int off[PG_PPT];
+#pragma unroll
+                for (int j = 0; j < PG_PPT; ++j) {
+                    const int ra = pr.world > 1 ? apv[j] / pr.Nl : 0;
+                    off[j] = apv[j] - ra * pr.Nl;
+                    rowp[j] = rebuild->la_p[ra];
+                }
+#pragma unroll
+                for (int j = 0; j < PG_PPT; ++j) lap[j] = rowp[j][off[j]];
+            }
+#pragma unroll
+            for (int j = 0; j < PG_PPT; ++j) {
+                const int i = PG_PPT * tid + j;
+                const double logw = rebuild->has_prev ? lnp[j] - lap[j] : 0.0;
+                const double l1 = las[j] + logw;
+                arg[j] = pgas_seg_arg(i < n ? l1 + hs[j] : -__builtin_inf(), kref);
+            }
         }
         pgas_exp_n(arg, ev, PG_PPT);
         uint64_t loc[PG_PPT], run = 0;
@@ -925,15 +973,33 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
             if (base_i + slot_of(tid, j) < N) st_stream(&ar.anc_out[base_i + slot_of(tid, j)], (int32_t)a[j]);
         }
         __syncthreads();
+        // log p(y_{t-1} | aux_{t-1}) of the ancestors: this device's row, or the owning peers' (src/PGAS.py:146).  Every slot holds a
+        // valid index (also past N), so the four gathers are issued together, unconditionally: a guarded load per particle makes the
+        // compiler wait for each in turn (eight dependent round trips instead of one or two).
+        int anv[PG_PPT];
+        double lav[PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) anv[r] = sm.u.a[r * PG_BLK + tid];
+        if (pr.world == 1) {   // uniform
+            const double* __restrict__ la0 = ar.anc_in.la_s[0];
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) lav[r] = la0[anv[r]];
+        } else {
+            const double* rowp[PG_PPT];
+            int off[PG_PPT];
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) {
+                const int ra = anv[r] / pr.Nl;
+                off[r] = anv[r] - ra * pr.Nl;
+                rowp[r] = ar.anc_in.la_s[ra];
+            }
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) lav[r] = rowp[r][off[r]];
+        }
 #pragma unroll
         for (int r = 0; r < PG_PPT; ++r) {
             const int64_t i = base_i + r * PG_BLK + tid;
-            if (i < N) {
-                // log p(y_{t-1} | aux_{t-1}) of the ancestor: this device's row, or the owning peer's (src/PGAS.py:146)
-                const int an = sm.u.a[r * PG_BLK + tid];
-                const int ra = pr.world > 1 ? an / pr.Nl : 0;
-                lwp[r] = lnv[r] - ar.anc_in.la_s[ra][an - (int64_t)ra * pr.Nl];
-            }
+            lwp[r] = i < N ? lnv[r] - lav[r] : 0.0;
         }
         PG_STAMP(5);
         if (ar.logw_out != nullptr) {
@@ -947,13 +1013,23 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
     }
     if (ar.mode & PG_RS_SCAN) {
         double lw[2][PG_PPT];
+        {
+            // the hand-off rows are padded to whole segments: eight unconditional loads in flight together
+            double lat[PG_PPT], ht[PG_PPT];
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
-            const size_t pi = (size_t)base_i + r * PG_BLK + tid;
-            const bool valid_p = pi < (size_t)N;
-            const double l1 = ld_stream(&ar.la_t[pi]) + lwp[r];
-            lw[0][r] = valid_p ? l1 : -__builtin_inf();
-            lw[1][r] = valid_p ? l1 + ld_stream(&ar.h_t[pi]) : -__builtin_inf();
+            for (int r = 0; r < PG_PPT; ++r) {
+                const size_t pi = (size_t)base_i + r * PG_BLK + tid;
+                lat[r] = ld_stream(&ar.la_t[pi]);
+                ht[r] = ld_stream(&ar.h_t[pi]);
+            }
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) {
+                const size_t pi = (size_t)base_i + r * PG_BLK + tid;
+                const bool valid_p = pi < (size_t)N;
+                const double l1 = lat[r] + lwp[r];
+                lw[0][r] = valid_p ? l1 : -__builtin_inf();
+                lw[1][r] = valid_p ? l1 + ht[r] : -__builtin_inf();
+            }
         }
         PG_STAMP(6);
         segment_scan<2, false, TAIL>(sm.u.scan, lw, seg, sb_next.nsegp, sb_next.c1, sb_next.c2, sb_next.segk_w, sb_next.segs_w);

@@ -3,13 +3,13 @@ the gaps between dependent launches on the chain stream.
 usage: timeline.py DIR"""
 import csv, glob, sys
 import numpy as np
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True)[0]
 rows = [r for r in csv.DictReader(open(f))]
 ev = {"k_step": [], "k_groups": [], "k_propagate": []}
 for r in rows:
     n = r["Kernel_Name"]
     for k in ev:
-        if k + "<" in n or n.startswith(k + "("):
+        if k + "<" in n or n.startswith(k + "(") or (k == "k_groups" and n.startswith("k_groups_abs")):
             ev[k].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 for k in ev:
     ev[k].sort()
