@@ -263,6 +263,11 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
         }
         const int gt = tid < PG_WIN_GRP ? tid : 0;
         const double g0 = gr[gt], g1 = gr[PG_ABS_WAVES + gt], g2 = gr[2 * PG_ABS_WAVES + gt];
+        PG_STAMP(9);
+#ifdef PG_STAMPS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PG_STAMP(10);
+#endif
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int wb = i * PG_BLK + tid;
@@ -367,8 +372,10 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
                 sm.g_lo = clo;
                 sm.g_hi = chi > n1 - 1 ? n1 - 1 : chi;
             }
+            PG_STAMP(9);
         }
         __syncthreads();
+        PG_STAMP(10);
         S = sm.S;
         const int g_lo = sm.g_lo, g_hi = sm.g_hi;
         int ngw = g_hi - g_lo + 1;   // <= 0 when every threshold lies beyond the total (cannot happen for U < 1, kept safe)
@@ -389,6 +396,7 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
             vsc[i] = sb.tab_sc[at];
             vm[i] = sb.tab_m[at];
         }
+        PG_STAMP(11);
 #pragma unroll
         for (int i = 0; i < PG_WIN_SEG / PG_BLK; ++i) {
             const int gw = wave + 4 * i, wb = (gw << 6) + lane, g = g_lo + gw, b = win_b0 + wb;
@@ -519,9 +527,14 @@ __device__ __forceinline__ double slot_U(double u1, int64_t i, int N, double inv
 // slot slot_of(tid, j), a GLOBAL particle index.  md.p0 / md.Ng / md.nseg_g place the device's shard in the global
 // particle range (single device: 0 / N / nseg).  Leaves LDS free for reuse after a trailing barrier of the caller.
 // ------------------------------------------------------------------------------------------
-template <int LOCAL>
+struct NoPrefetch {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `prefetch` is called once, right after the window's loads have come back: the place for loads the caller needs only after the
+// search (issued any earlier they sit in front of the window's loads in the in-order vmcnt queue and delay them by an HBM miss).
+template <int LOCAL, class PF = NoPrefetch>
 __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOCAL>& sm, double u1, const ScanBufs& sb, const Peers& pr,
-                                                int seg, int (&a)[PG_PPT]) {
+                                                int seg, int (&a)[PG_PPT], PF prefetch = PF()) {
     const int tid = threadIdx.x;
     const int nseg = md.nseg_g, N = md.Ng;
     const bool pow2 = (N & (N - 1)) == 0;
@@ -533,6 +546,7 @@ __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOC
     double S;
     int win_b0, nwin;
     const bool covered = window_head<LOCAL>(sm, sb, 0, nseg, U_first, U_last, S, win_b0, nwin);
+    prefetch();
     PG_STAMP(1);
     const bool valid = (S > 0.0) && (S < __builtin_inf());
     double tau[PG_PPT];
@@ -932,14 +946,17 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
     const int seg = blockIdx.x - 1;
     const int64_t base_i = (int64_t)seg * PGAS_SEG;
     PG_STAMP(0);
-    // own-particle inputs first: their latency overlaps the scans below
-    double lnv[PG_PPT];
-#pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) lnv[r] = (ar.mode & PG_RS_SEARCH) ? ld_stream(&ar.ln_prev[(size_t)base_i + r * PG_BLK + tid]) : 0.0;
+    // ln_{t-1} of the own particles is loaded inside the search, behind the window's loads (unconditionally: the rows are padded to
+    // whole segments).  Issued first thing and behind a `mode & SEARCH ?` guard, the compiler waited for every one of them at the join:
+    // two HBM round trips before the window was even started.
+    double lnv[PG_PPT] = {0.0, 0.0, 0.0, 0.0};
     double lwp[PG_PPT] = {0.0, 0.0, 0.0, 0.0};
     if (ar.mode & PG_RS_SEARCH) {
         int a[PG_PPT];
-        resample_search<LOCAL>(md, sm, ar.u1_prev, sb_prev, pr, seg, a);
+        resample_search<LOCAL>(md, sm, ar.u1_prev, sb_prev, pr, seg, a, [&]() {
+#pragma unroll
+            for (int r = 0; r < PG_PPT; ++r) lnv[r] = ld_stream(&ar.ln_prev[(size_t)base_i + r * PG_BLK + tid]);
+        });
         const bool last_wg = md.p0 + base_i + PGAS_SEG >= md.Ng;  // uniform: owns the conditioned particle
         if (last_wg) {
             // ancestor of the conditioned particle, published by workgroup 0 (src/PGAS.py:127)

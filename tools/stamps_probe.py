@@ -34,6 +34,8 @@ d = np.diff(st[:, :6], axis=1) / 100.0
 print("per-phase durations (us), median over workgroups:", dict(zip(names[1:], np.round(np.median(d, axis=0), 2))))
 print(f"end of the last launch (search only): median {np.median(rel[:, 7]):.2f}, max {rel[:, 7].max():.2f} us")
 print(f"scan phase of the launch before (stamps 6 -> 8): median {np.median((st[:, 8] - st[:, 6]) / 100.0):.2f} us, p95 {np.percentile((st[:, 8] - st[:, 6]) / 100.0, 95):.2f}")
+if st[:, 9].max() > 0:
+    print("window_head detail (us after start, median): top scan done (wave 0) %.2f, after barrier %.2f, tab loads issued %.2f, window filled %.2f" % tuple(np.median(rel[:, i] - rel[:, 0]) for i in (9, 10, 11, 1)))
 tot = rel[:, 5] - rel[:, 0]
 print("start -> gathered per workgroup (us): " + "  ".join(f"p{q}: {np.percentile(tot, q):.2f}" for q in (50, 75, 90, 95, 99, 99.9)) + f"  max {tot.max():.2f}")
 rounds = (st[:, 3] - st[:, 2]) / 100.0
