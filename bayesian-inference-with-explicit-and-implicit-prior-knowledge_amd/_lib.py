@@ -488,7 +488,7 @@ class Engine:
         """dict(chunk, local_groups, JP, P) of the last sweep (pgas_get_launch_info)."""
         v = (C.c_int32 * 4)()
         self._chk(self.lib.pgas_get_launch_info(self._h, v), "pgas_get_launch_info")
-        return dict(chunk=int(v[0]), local_groups=int(v[1]) == 1, groups={0: "k_groups", 1: "local", 2: "tail", 3: "abs"}[int(v[1])], JP=int(v[2]), P=int(v[3]))
+        return dict(chunk=int(v[0]), local_groups=int(v[1]) == 1, groups={0: "k_groups", 1: "local", 2: "tail"}[int(v[1])], JP=int(v[2]), P=int(v[3]))
 
     def shard_sweep(self, seed, ref, traj, propagate_chunk=0):
         self._ag_error = None

@@ -215,7 +215,6 @@ struct pgas_ctx {
     int last_chunk = 0;         // time steps per k_propagate launch of the last sweep
     int var_P = 0;              // particles per basis pass of the k_propagate variant
     unsigned launch_tag = 0;    // unique id per k_step launch (hand-off word tag)
-    int no_abs = 1;             // development knob (PGAS_ABS=1 in the environment at pgas_create selects the absolute-record path)
     int force_slow = 0;         // 1: never let k_step scan the groups itself (test hook for the k_groups path taken when N > 2^20 per device)
     int tail_groups = 0;        // PGAS_OPT_TAIL_GROUPS: 1 = group scans in k_step's tail instead of k_groups launches (single device; slower, kept as an experiment)
     int ev_stride = 8;          // PGAS_OPT_EVENT_STRIDE: k_propagate launches per event that gates the weight recursion
@@ -278,9 +277,6 @@ static int alloc_scanbufs(pgas_ctx* c, ScanBufs* sb) {
     HIPCHK(c, hipMalloc(&sb->tab_e, 2 * nsegp * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->tab_sc, 2 * nsegp * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->tab_m, 2 * nsegp * sizeof(double)));
-    HIPCHK(c, hipMalloc(&sb->abs_cm, 2 * nsegp * sizeof(double)));
-    HIPCHK(c, hipMalloc(&sb->abs_dexp, 2 * nsegp * sizeof(int32_t)));
-    HIPCHK(c, hipMalloc(&sb->abs_grp, 2 * 4 * PG_ABS_WAVES * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->grp_K, 2 * PG_MAX_GRP * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->grp_T, 2 * PG_MAX_GRP * sizeof(double)));
     HIPCHK(c, hipMalloc(&sb->grp_cnt, PG_MAX_GRP * sizeof(unsigned)));
@@ -296,7 +292,6 @@ static int alloc_scanbufs(pgas_ctx* c, ScanBufs* sb) {
 }
 static void free_scanbufs(ScanBufs* sb) {
     hipFree(sb->laux); hipFree(sb->c1); hipFree(sb->c2); hipFree(sb->segk_w); hipFree(sb->segs_w);  // segk/segs alias these or the gathered arrays
-    hipFree(sb->abs_cm); hipFree(sb->abs_dexp); hipFree(sb->abs_grp);
     hipFree(sb->tab_e); hipFree(sb->tab_sc); hipFree(sb->tab_m); hipFree(sb->grp_K); hipFree(sb->grp_T); hipFree(sb->grp_cnt); hipFree(sb->hdr);
     *sb = ScanBufs{};
 }
@@ -358,7 +353,6 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
     c->init = d->nx == 1 ? k_init<1> : k_init<2>;
     c->basis = d->nx == 1 ? k_basis_eval<1> : k_basis_eval<2>;
     c->keep_logw = d->keep_logw_trace;
-    { const char* e = getenv("PGAS_ABS"); c->no_abs = !(e && e[0] == '1'); }   // absolute-record path: opt-in while it measures slower
 
     c->device = d->device;
     // grid positions of the basis functions, innermost dimension padded to JP
@@ -591,13 +585,6 @@ static int launch_count(pgas_ctx* c, const ScanBufs& sb, int parity, int what, d
 // issue than the extra tiny launch costs latency).  PGAS_OPT_LOCAL_GROUPS selects it.
 static bool sweep_is_local(const pgas_ctx* c) { return c->local_groups && c->world == 1 && !c->sharded && c->md.nseg_g <= PG_LOCAL_NSEG && !c->force_slow; }
 
-// Default on one device with <= 1024 segments: k_groups_abs between the steps (absolute records, one workgroup) and k_step<PG_WM_ABS>,
-// whose workgroups fill their window with one round of loads.  PGAS_OPT_FORCE_SLOW_RESAMPLE keeps the general path (k_groups + a top
-// scan per workgroup: what larger devices and sharded sweeps run) so that the tests can exercise it at small sizes.
-static bool sweep_is_abs(const pgas_ctx* c) {
-    return !c->sharded && c->world == 1 && c->md.nseg_g <= PG_WIN_SEG && !c->force_slow && !c->local_groups && !c->tail_groups && !c->no_abs;
-}
-
 // PGAS_OPT_TAIL_GROUPS (single device only; sharded sweeps need the all-gather first): the group scans ride in k_step's tail, done by
 // the workgroup that completes a group, instead of a k_groups launch between the steps.  Correct and bit-identical, but measured
 // SLOWER (88.5 against 84.9 ms per sweep at N = 2^20: the write-through stores, the drain and the returning atomic at the end of
@@ -636,7 +623,6 @@ static int launch_step(pgas_ctx* c, int t, uint64_t seed, bool local, hipStream_
     const Peers pr = peers_for(c, (t - 1) & 1);
     if (local) hipExtLaunchKernelGGL((k_step<PG_WM_LOCAL, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
     else if (sweep_tail_groups(c)) hipExtLaunchKernelGGL((k_step<PG_WM_GROUPS, true>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
-    else if (sweep_is_abs(c)) hipExtLaunchKernelGGL((k_step<PG_WM_ABS, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
     else hipExtLaunchKernelGGL((k_step<PG_WM_GROUPS, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
     KCHK(c, "k_step");
     return PGAS_OK;
@@ -846,13 +832,8 @@ static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int 
                     rc = shard_all_gather(c, t & 1, sB);   // the one collective of the step, stream-ordered: no host round trip
                     if (rc) return rc;
                 }
-                if (sweep_is_abs(c)) {
-                    hipLaunchKernelGGL(k_groups_abs, dim3(1), dim3(64 * PG_ABS_WAVES), 0, sB, md.nseg_g, 2, c->sb[t & 1]);
-                    KCHK(c, "k_groups_abs");
-                } else {
-                    rc = launch_groups(c, c->sb[t & 1], 2, sB);
-                    if (rc) return rc;
-                }
+                rc = launch_groups(c, c->sb[t & 1], 2, sB);
+                if (rc) return rc;
             }
         }
         if (lead > 0) HIPCHK(c, hipEventRecord(c->ev_bdone[gi], sB));
@@ -1086,7 +1067,7 @@ int pgas_get_launch_info(pgas_ctx* c, int32_t* info4) {
     if (!c) return PGAS_E_ARG;
     if (!info4) FAIL(c, PGAS_E_ARG, "pgas_get_launch_info: NULL argument");
     info4[0] = c->last_chunk;
-    info4[1] = sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : (sweep_is_abs(c) ? 3 : 0));
+    info4[1] = sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0);
     info4[2] = c->md.JP;
     info4[3] = c->var_P;
     return PGAS_OK;

@@ -141,9 +141,6 @@ struct ScanBufs {      // per-step scan scratch (device)
     double* tab_e;     // (2, nsegp_g) per-segment records written by k_groups: exclusive prefix inside the group,
     double* tab_sc;    //              scale 2^(kref - KG),
     double* tab_m;     //              running maximum of the segment-end values inside the group
-    double* abs_cm;    // (2, nsegp_g) k_groups_abs: running maximum at the segment's end on the scale of the total S (tab_m then holds the
-    int32_t* abs_dexp; //              running maximum BEFORE the segment), log2 of the segment's scale (PG_DEXP_ZERO: scale 0),
-    double* abs_grp;   // (2, 4, 16)   per group E, sigma, CM of the group before; [3][0] = S
     double* grp_K;     // (2, PG_MAX_GRP) group references KG
     double* grp_T;     // (2, PG_MAX_GRP) group totals TG
     unsigned* grp_cnt; // (PG_MAX_GRP) arrival counters of k_step's in-launch group scans (zero between uses)

@@ -140,75 +140,12 @@ __global__ __launch_bounds__(256) void k_groups(int nseg, int ncdf, ScanBufs sb)
     group_records_wave(sb, nseg, w / n1, w % n1, false);
 }
 
-// k_groups_abs: the same records for a device whose CDF fits ONE search window (nseg <= 1024, i.e. <= 16 groups), in ABSOLUTE form.
-// One workgroup of 16 waves: wave w scans group w, the (KG, TG) records meet in LDS, every wave repeats the (16-lane) top scan
-// and then finishes its own group: what k_step's window needs per segment -- running maximum cm at the segment's end on the scale
-// of the total S, exclusive prefix e, running maximum mp before it, log2 of the scale -- and per group (E, sigma, CM before), plus S.
-// A k_step workgroup then fills its window with ONE round of independent loads and no scan of its own (window mode PG_WM_ABS);
-// with k_groups it needs the group records, a top scan by one wave and a second, dependent round of loads.  Same values bit for bit.
-#define PG_ABS_WAVES (PG_WIN_SEG / PG_GRP)
-__global__ __launch_bounds__(64 * PG_ABS_WAVES) void k_groups_abs(int nseg, int ncdf, ScanBufs sb) {
-    __shared__ double sK[2][PG_ABS_WAVES], sT[2][PG_ABS_WAVES];
-    __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int n1 = (nseg + PG_GRP - 1) / PG_GRP;
-    const int b = g * PG_GRP + lane;
-    double e[2], sc[2], m[2];
-#pragma unroll
-    for (int cdf = 0; cdf < 2; ++cdf) {
-        if (cdf >= ncdf) break;   // uniform
-        double kk = -__builtin_inf();
-        uint64_t ss = 0;
-        if (b < nseg) {
-            const size_t at = partial_at(sb, cdf, b);
-            kk = sb.segk[at];
-            ss = sb.segs[at];
-        }
-        double Kg;
-        group_scan_wave(kk, ss, e[cdf], sc[cdf], m[cdf], Kg);
-        int nb = nseg - g * PG_GRP;
-        nb = nb < 1 ? 1 : (nb > PG_GRP ? PG_GRP : nb);
-        const double Tg = readlane_f64(m[cdf], nb - 1);
-        if (lane == 0) {
-            sK[cdf][g] = g < n1 ? Kg : -__builtin_inf();
-            sT[cdf][g] = g < n1 ? Tg : 0.0;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int cdf = 0; cdf < 2; ++cdf) {
-        if (cdf >= ncdf) break;   // uniform
-        const double Kg2[2] = {lane < n1 ? sK[cdf][lane & (PG_ABS_WAVES - 1)] : -__builtin_inf(), -__builtin_inf()};
-        const double Tg2[2] = {lane < n1 ? sT[cdf][lane & (PG_ABS_WAVES - 1)] : 0.0, 0.0};
-        double E[2], sig[2], CM[2];
-        const double S = top_scan_wave(n1, Kg2, Tg2, E, sig, CM);
-        const double Eg = readlane_f64(E[0], g), sg = readlane_f64(sig[0], g), cpr = readlane_f64(CM[0], g ? g - 1 : 0);
-        const double cp = g ? cpr : 0.0;
-        const double upm = __shfl_up(m[cdf], 1), upc = __shfl_up(CM[0], 1);
-        const size_t o = (size_t)cdf * sb.nsegp_g + b;
-        if (b < nseg) {
-            sb.abs_cm[o] = __builtin_fmax(cp, Eg + sg * m[cdf]);
-            sb.tab_e[o] = e[cdf];
-            sb.tab_m[o] = lane ? upm : 0.0;            // ABSOLUTE layout: tab_m holds mp (the running maximum BEFORE the segment)
-            sb.abs_dexp[o] = dexp_of(sc[cdf]);
-        }
-        if (g == 0 && lane < PG_ABS_WAVES) {
-            double* gr = sb.abs_grp + (size_t)cdf * 4 * PG_ABS_WAVES;
-            gr[lane] = E[0];
-            gr[PG_ABS_WAVES + lane] = sig[0];
-            gr[2 * PG_ABS_WAVES + lane] = lane ? upc : 0.0;
-            if (lane == 0) gr[3 * PG_ABS_WAVES] = S;
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // Search window of a workgroup (256 threads) in LDS
 // ------------------------------------------------------------------------------------------
 // how the window of a workgroup is filled
 #define PG_WM_GROUPS 0   // group records of k_groups + a top scan by one wave: any size, any number of ranks
 #define PG_WM_LOCAL 1    // every workgroup scans all groups itself from the raw partials (single device, <= 1024 segments)
-#define PG_WM_ABS 2      // absolute records of k_groups_abs, one round of loads (single device, <= 1024 segments)
 template <int LOCAL>
 struct WinSmemT {
     double cm[PG_WIN_SEG];   // running maximum of the CDF at the end of every window segment, +inf beyond the window
@@ -243,55 +180,7 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
                                             double& S, int& win_b0, int& nwin) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n1 = (nseg + PG_GRP - 1) / PG_GRP;
-    if constexpr (LOCAL == PG_WM_ABS) {
-        // everything was finished by k_groups_abs: one round of independent, coalesced loads
-        const size_t o = (size_t)cdf * sb.nsegp_g;
-        const double* __restrict__ gr = sb.abs_grp + (size_t)cdf * 4 * PG_ABS_WAVES;
-        S = gr[3 * PG_ABS_WAVES];
-        // all loads first, unconditionally (clamped indices): a guarded load per array and row makes the compiler wait for each in turn
-        constexpr int NR = PG_WIN_SEG / PG_BLK;
-        double vcm[NR], ve[NR], vmp[NR];
-        int vdx[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int wb = i * PG_BLK + tid;
-            const size_t at = o + (wb < nseg ? wb : nseg - 1);
-            vcm[i] = sb.abs_cm[at];
-            ve[i] = sb.tab_e[at];
-            vmp[i] = sb.tab_m[at];
-            vdx[i] = sb.abs_dexp[at];
-        }
-        const int gt = tid < PG_WIN_GRP ? tid : 0;
-        const double g0 = gr[gt], g1 = gr[PG_ABS_WAVES + gt], g2 = gr[2 * PG_ABS_WAVES + gt];
-        PG_STAMP(9);
-#ifdef PG_STAMPS
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        PG_STAMP(10);
-#endif
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int wb = i * PG_BLK + tid;
-            const bool in = wb < nseg;
-            sm.cm[wb] = in ? vcm[i] : __builtin_inf();
-            sm.u.tab.e[wb] = in ? ve[i] : 0.0;
-            sm.u.tab.mp[wb] = in ? vmp[i] : 0.0;
-            sm.dexp[wb] = (short)(in ? vdx[i] : PG_DEXP_ZERO);
-        }
-        if (tid < PG_WIN_GRP) {
-            sm.gE[tid] = g0;
-            sm.gS[tid] = g1;
-            sm.gCP[tid] = g2;
-        }
-        __syncthreads();
-        win_b0 = 0;
-        nwin = nseg;
-        (void)U_first;
-        (void)U_last;
-        (void)n1;
-        (void)lane;
-        (void)wave;
-        return true;
-    } else if constexpr (LOCAL == PG_WM_LOCAL) {
+    if constexpr (LOCAL == PG_WM_LOCAL) {
         double mreg[PG_WIN_GRP / 4];
 #pragma unroll
         for (int e4 = 0; e4 < PG_WIN_GRP / 4; ++e4) {
@@ -385,29 +274,16 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
         nwin = ngw * PG_GRP < nseg - win_b0 ? ngw * PG_GRP : nseg - win_b0;
         if (nwin < 0) nwin = 0;
         const size_t o = (size_t)cdf * sb.nsegp_g;
-        // the records of all (up to sixteen) window groups in one round of loads: clamped indices, no guards around the loads
+        // The records of the window's groups, one row of loads per four groups (wave w takes groups w, w + 4, ...), clamped indices and
+        // no guard around a load: guarded loads make the compiler wait for each in turn.  A window is one or two groups almost always,
+        // so the usual case issues ONE row (three loads per lane); loading all sixteen groups regardless costs 24 KB of L1 traffic per
+        // workgroup, 0.7 us when the four workgroups of a CU do it at once.
         constexpr int NR = PG_WIN_SEG / PG_BLK;
-        double ve[NR], vsc[NR], vm[NR];
-#pragma unroll
-        for (int i = 0; i < NR; ++i) {
-            const int b = win_b0 + ((wave + 4 * i) << 6) + lane;
-            const size_t at = o + (size_t)(b < nseg ? b : nseg - 1);
-            ve[i] = sb.tab_e[at];
-            vsc[i] = sb.tab_sc[at];
-            vm[i] = sb.tab_m[at];
-        }
-        PG_STAMP(11);
-#pragma unroll
-        for (int i = 0; i < PG_WIN_SEG / PG_BLK; ++i) {
+        auto fill = [&](int i, double e, double sc, double m) {
             const int gw = wave + 4 * i, wb = (gw << 6) + lane, g = g_lo + gw, b = win_b0 + wb;
             double cmv = __builtin_inf();
             if (gw < ngw) {   // wave-uniform
-                double e = 0.0, sc = 0.0, m = 0.0;
-                if (b < nseg) {
-                    e = ve[i];
-                    sc = vsc[i];
-                    m = vm[i];
-                }
+                if (b >= nseg) e = 0.0, sc = 0.0, m = 0.0;
                 const double upm = __shfl_up(m, 1);
                 const double Eg = sm.topE[g], sg = sm.topS[g], cp = g ? sm.topCM[g - 1] : 0.0;
                 if (b < nseg) cmv = __builtin_fmax(cp, Eg + sg * m);
@@ -421,6 +297,29 @@ __device__ __forceinline__ bool window_head(WinSmemT<LOCAL>& sm, const ScanBufs&
                 }
             }
             sm.cm[wb] = cmv;
+        };
+        auto at_of = [&](int i) {
+            const int b = win_b0 + ((wave + 4 * i) << 6) + lane;
+            return o + (size_t)(b < nseg ? b : nseg - 1);
+        };
+        if (ngw <= 4) {   // uniform
+            const size_t at = at_of(0);
+            const double e = sb.tab_e[at], sc = sb.tab_sc[at], m = sb.tab_m[at];
+            PG_STAMP(11);
+            fill(0, e, sc, m);
+#pragma unroll
+            for (int i = 1; i < NR; ++i) sm.cm[((wave + 4 * i) << 6) + lane] = __builtin_inf();
+        } else {
+            double ve[NR], vsc[NR], vm[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                const size_t at = at_of(i);
+                ve[i] = sb.tab_e[at];
+                vsc[i] = sb.tab_sc[at];
+                vm[i] = sb.tab_m[at];
+            }
+#pragma unroll
+            for (int i = 0; i < NR; ++i) fill(i, ve[i], vsc[i], vm[i]);
         }
         __syncthreads();
         return covered;
