@@ -63,7 +63,9 @@ class condSequentialMonteCarlo:
 
     # src/PGAS.py:176-228
     def __call__(self, key, ref_state, coeff_mat, error_cov):
-        """Whole sweep on the device; returns the sampled trajectory (T,nx), squeezed like the reference."""
+        """Whole sweep on the device; returns the sampled trajectory (T,nx), squeezed like the reference.  With coeff_mat / error_cov
+        already on the device (PGAS.sample_params) nothing in here touches the host: error_cov is factored by the pack kernel
+        (pgas_set_params_dev) and the sweep itself is one replayed HIP graph."""
         self.engine.set_params(coeff_mat, error_cov)
         ref = ref_state if isinstance(ref_state, torch.Tensor) else torch.as_tensor(np.asarray(ref_state, dtype=np.float64))
         traj = self.engine.sweep(prng.as_key(key), ref.reshape(self.engine.T, self.engine.nx))
@@ -106,7 +108,8 @@ class PGAS:
         dev = eng.device
         T0, T1, T2, T3 = eng.suffstats(state_trajectory)                      # :294-303
         e0, e1, e2, e3 = self.GP_prior[0] + T0, self.GP_prior[1] + T1, self.GP_prior[2] + T2, self.GP_prior[3] + T3
-        Lc = torch.linalg.cholesky(e1)                                         # BI:35-45
+        # cholesky_ex: no host-side error check, i.e. no synchronisation inside a Gibbs iteration (a failed factorisation shows up as NaNs)
+        Lc = torch.linalg.cholesky_ex(e1, check_errors=False)[0]               # BI:35-45
         sol = torch.cholesky_solve(torch.cat([e0, self._eye[0]], dim=1), Lc)
         mean, col_cov = sol[:, : eng.nx].T.contiguous(), sol[:, eng.nx:]
         row_scale = e2 - mean @ e0
@@ -114,12 +117,12 @@ class PGAS:
             draws = self.param_draws(key)
         g = lambda a: a if isinstance(a, torch.Tensor) else torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)  # noqa: E731
         eye = self._eye[1]
-        L = torch.linalg.solve_triangular(torch.linalg.cholesky(row_scale), eye, upper=False)      # :317-319
+        L = torch.linalg.solve_triangular(torch.linalg.cholesky_ex(row_scale, check_errors=False)[0], eye, upper=False)      # :317-319
         Tm = torch.tril(g(draws["normals_T"]), diagonal=-1) + torch.diag(torch.sqrt(g(draws["chi2"])))  # :327-329
         Cm = L @ Tm                                                            # :332
         S_chol = torch.linalg.solve_triangular(Cm.T.contiguous(), eye, upper=True)  # :334
         S = S_chol @ S_chol.T                                                  # :335
-        V_chol = torch.linalg.cholesky(col_cov)                                # :339
+        V_chol = torch.linalg.cholesky_ex(col_cov, check_errors=False)[0]      # :339
         A = mean + S_chol @ g(draws["normals_A"]) @ V_chol                     # :341 (Q5)
         self.last_df = e3
         return A, S

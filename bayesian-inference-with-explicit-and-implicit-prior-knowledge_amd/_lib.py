@@ -33,7 +33,7 @@ class _ModelDesc(C.Structure):
 
 
 EXPORTS = [
-    "pgas_create", "pgas_destroy", "pgas_last_error", "pgas_segment_size", "pgas_set_params", "pgas_basis_eval",
+    "pgas_create", "pgas_destroy", "pgas_last_error", "pgas_segment_size", "pgas_set_params", "pgas_set_params_dev", "pgas_get_params", "pgas_basis_eval",
     "pgas_aux_states", "pgas_init_state", "pgas_step", "pgas_sweep", "pgas_get_traces", "pgas_last_final_index",
     "pgas_suffstats", "pgas_set_profiling", "pgas_get_profile", "pgas_set_option",
     "pgas_systematic_resample", "pgas_reconstruct_trajectory",
@@ -56,6 +56,19 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise PgasError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` (hipcc, gfx950); there is no CPU fallback")
     L = C.CDLL(LIB_PATH)
+
+    class _Missing:   # an older build (tools/ab_bench.py variants) may lack newer entry points: they fail when called, not at load time
+        restype = argtypes = None
+
+        def __init__(self, name):
+            self.name = name
+
+        def __call__(self, *a):
+            raise PgasError(f"{LIB_PATH} does not export {self.name}")
+
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            setattr(L, name, _Missing(name))
     vp, u64, i32, i64 = C.c_void_p, C.c_uint64, C.c_int32, C.c_int64
     L.pgas_create.restype = C.c_int
     L.pgas_create.argtypes = [C.POINTER(_ModelDesc), C.POINTER(vp)]
@@ -66,6 +79,10 @@ def load():
     L.pgas_segment_size.restype = i32
     L.pgas_set_params.restype = C.c_int
     L.pgas_set_params.argtypes = [vp, vp, _dp, _dp, C.c_double, vp]
+    L.pgas_set_params_dev.restype = C.c_int
+    L.pgas_set_params_dev.argtypes = [vp, vp, vp, vp]
+    L.pgas_get_params.restype = C.c_int
+    L.pgas_get_params.argtypes = [vp, _dp, _dp, _dp, vp]
     L.pgas_basis_eval.restype = C.c_int
     L.pgas_basis_eval.argtypes = [vp, vp, i64, i32, vp, vp]
     L.pgas_aux_states.restype = C.c_int
@@ -259,8 +276,16 @@ class Engine:
 
     # -------------------------------------------------------------- calls
     def set_params(self, coeff_mat, error_cov):
-        """coeff_mat (nx,M) tensor/array, error_cov (nx,nx)."""
+        """coeff_mat (nx,M) tensor/array, error_cov (nx,nx).  An error_cov that already lives on the engine's device is factored THERE
+        (pgas_set_params_dev: no synchronisation, no host round trip -- the Gibbs loop's case) and None is returned; a host array is
+        factored with NumPy and (LS, LSinv, cS) returned.  The two factorisations agree to rounding, not bit for bit: get_params() reads
+        back what the kernels use."""
         A = self._dev(coeff_mat, shape=(self.nx, self.M))
+        if isinstance(error_cov, torch.Tensor) and error_cov.is_cuda and error_cov.device == self.device and os.environ.get("PGAS_HOST_PARAMS", "0") != "1":
+            Sd = error_cov.detach().to(torch.float64).reshape(self.nx, self.nx).contiguous()
+            self._A, self._S = A, Sd   # keep alive until the pack kernel has run
+            self._chk(self.lib.pgas_set_params_dev(self._h, A.data_ptr(), Sd.data_ptr(), self._stream()), "pgas_set_params_dev")
+            return None
         S = np.atleast_2d(np.asarray(error_cov.detach().cpu() if isinstance(error_cov, torch.Tensor) else error_cov, dtype=np.float64))
         LS = _f64(np.linalg.cholesky(S))
         LSinv = _f64(np.linalg.inv(LS))
@@ -268,6 +293,12 @@ class Engine:
         self._A = A  # keep alive until the pack kernel has run
         self._chk(self.lib.pgas_set_params(self._h, A.data_ptr(), _hp(LS), _hp(LSinv), cS, self._stream()), "pgas_set_params")
         return LS, LSinv, cS
+
+    def get_params(self):
+        """(LS, LSinv, cS) the kernels currently use (synchronises): Cholesky factor of error_cov, its inverse, the normalising constant."""
+        LS, LSinv, cS = np.zeros((self.nx, self.nx)), np.zeros((self.nx, self.nx)), C.c_double()
+        self._chk(self.lib.pgas_get_params(self._h, _hp(LS), _hp(LSinv), C.byref(cS), self._stream()), "pgas_get_params")
+        return LS, LSinv, float(cS.value)
 
     def basis_eval(self, x, t):
         x = self._dev(x).reshape(-1, self.nx)
@@ -488,7 +519,8 @@ class Engine:
         """dict(chunk, local_groups, JP, P) of the last sweep (pgas_get_launch_info)."""
         v = (C.c_int32 * 4)()
         self._chk(self.lib.pgas_get_launch_info(self._h, v), "pgas_get_launch_info")
-        return dict(chunk=int(v[0]), local_groups=int(v[1]) == 1, groups={0: "k_groups", 1: "local", 2: "tail"}[int(v[1])], JP=int(v[2]), P=int(v[3]))
+        g = int(v[1]) & 15
+        return dict(chunk=int(v[0]), local_groups=g == 1, groups={0: "k_groups", 1: "local", 2: "tail"}[g], graph=bool(int(v[1]) & 16), JP=int(v[2]), P=int(v[3]))
 
     def shard_sweep(self, seed, ref, traj, propagate_chunk=0):
         self._ag_error = None

@@ -89,12 +89,12 @@ struct DeviceGuard {
     DeviceGuard& operator=(const DeviceGuard&) = delete;
 };
 
-typedef void (*front_fn)(DevModel, TransParams, int, uint64_t, const double*, const double*, const double*, int, double*, ScanBufs);
-typedef void (*backc_fn)(DevModel, TransParams, int, uint64_t, double, const double*, const double*, ScanBufs, Peers, int32_t*, double*, double*);
-typedef void (*prop_fn)(DevModel, TransParams, uint64_t, int, int, const double*, double*, const double*, double*, double*, double*);
-typedef void (*aux_fn)(DevModel, TransParams, int, const double*, double*);
+typedef void (*front_fn)(DevModel, const TransParams*, int, uint64_t, const double*, const double*, const double*, int, double*, ScanBufs);
+typedef void (*backc_fn)(DevModel, const TransParams*, int, uint64_t, double, const double*, const double*, ScanBufs, Peers, int32_t*, double*, double*);
+typedef void (*prop_fn)(DevModel, const TransParams*, const double*, const SweepParams*, int, int, const double*, double*, const double*, double*, double*, double*);
+typedef void (*aux_fn)(DevModel, const TransParams*, int, const double*, double*);
 typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, Peers, int32_t*, double*);
-typedef void (*init_fn)(DevModel, uint64_t, const double*, const double*, double*);
+typedef void (*init_fn)(DevModel, uint64_t, const SweepParams*, const double*, const double*, double*);
 typedef void (*basis_fn)(DevModel, const int32_t*, const double*, int64_t, int, double*);
 
 struct Variant {
@@ -157,6 +157,11 @@ struct RowStore {
     }
 };
 #define PG_TRACE_BLOCK_BYTES ((size_t)1 << 30)
+// PGAS_OPT_GRAPH automatic: replay the captured sweep up to this many particles.  Measured (PyTorch 2.10's bundled HIP 7.0 runtime,
+// T = 2000): at N = 2^20 the replay is SLOWER than enqueueing -- hipGraphLaunch itself blocks the host for 53 ms (eager enqueue: 45 ms)
+// and the replayed sweep takes 92 ms on the device against 66-70 ms (the two pipelines no longer overlap as well) -- so large sweeps
+// stay on the eager path; DESIGN.md section 8 has the small-N figures.
+#define PG_GRAPH_AUTO_N 0
 
 }  // namespace
 
@@ -187,7 +192,25 @@ struct pgas_ctx {
     double* d_ref = nullptr;   // nx doubles: ref_t of pgas_step / ref0 of pgas_init_state
     double* d_G = nullptr;
     int64_t gtotal = 0;        // doubles in d_G
-    TransParams tp{};
+    TransParams tp{};           // host mirror of what pgas_set_params was given (pgas_set_params_dev: only G is meaningful)
+    TransParams* d_tp = nullptr;   // THE transition parameters every kernel reads (k_pack writes them)
+    SweepParams* d_sp = nullptr;   // per-sweep scalars (k_sweep_begin)
+    double* d_ures = nullptr;      // (T + 1) resampling uniforms of the running sweep
+    double* d_uanc = nullptr;      // (T + 1) ancestor uniforms
+    uint32_t epoch = 0;            // sweeps started on this context
+    // captured sweep (PGAS_OPT_GRAPH): k_init ... k_backtrace of pgas_sweep as one HIP graph, replayed per sweep; the reference
+    // trajectory and the result go through library-owned buffers because the caller's pointers change from call to call
+    int use_graph = -1;            // PGAS_OPT_GRAPH: 1 on, 0 off, -1 automatic (see pgas_sweep)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_key[6] = {-1, -1, -1, -1, -1, -1};   // launch configuration the graph was captured with
+    int last_graph = 0;            // 1: the last pgas_sweep replayed the captured graph
+    int graph_failed = 0;          // capture or instantiation failed once: stay on the eager path
+    hipStream_t sG = nullptr;      // the stream captured sweeps are recorded on and replayed on (the caller's may be the legacy default
+                                   // stream, which cannot be captured); ordered against the caller's stream with ev_g0 / ev_g1
+    hipEvent_t ev_g0 = nullptr, ev_g1 = nullptr;
+    double* d_refbuf = nullptr;    // (T, nx)
+    double* d_trajbuf = nullptr;   // (T, nx)
     bool have_params = false;
     ScanBufs sb[2]{};
     // traces: rs[PG_RB_X] (T rows of (N, nx)), rs[PG_RB_ANC] (T-1 rows of N int32), and the hand-off rows k_propagate writes for the
@@ -399,6 +422,14 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
     HIPCHK(c, hipMalloc(&c->d_m0L0, m0L0.size() * sizeof(double)));
     HIPCHK(c, hipMemcpy(c->d_m0L0, m0L0.data(), m0L0.size() * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(c, hipMalloc(&c->d_ref, 4 * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_tp, sizeof(TransParams)));
+    HIPCHK(c, hipMalloc(&c->d_sp, sizeof(SweepParams)));
+    HIPCHK(c, hipMemset(c->d_sp, 0, sizeof(SweepParams)));
+    HIPCHK(c, hipMalloc(&c->d_ures, ((size_t)d->T + 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_uanc, ((size_t)d->T + 1) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_refbuf, (size_t)d->T * d->nx * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->d_trajbuf, (size_t)d->T * d->nx * sizeof(double)));
+    { const char* e = getenv("PGAS_GRAPH"); if (e && (e[0] == '0' || e[0] == '1')) c->use_graph = e[0] - '0'; }   // development knob
     for (int i = 0; i < 2; ++i) {
         int rc = alloc_scanbufs(c, &c->sb[i]);
         if (rc) return rc;
@@ -428,6 +459,12 @@ void pgas_destroy(pgas_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
     hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_qdesc); hipFree(c->d_m0L0); hipFree(c->d_ref);
+    if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
+    if (c->graph) (void)hipGraphDestroy(c->graph);
+    if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
+    if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
+    if (c->sG) (void)hipStreamDestroy(c->sG);
+    hipFree(c->d_tp); hipFree(c->d_sp); hipFree(c->d_ures); hipFree(c->d_uanc); hipFree(c->d_refbuf); hipFree(c->d_trajbuf);
     hipFree(c->d_G); hipFree(c->logw_last); hipFree(c->logw_trace); hipFree(c->d_bt);
     for (RowStore& r : c->rs) r.release();
     hipFree(c->segk_g[0]); hipFree(c->segk_g[1]); hipFree(c->segs_g[0]); hipFree(c->segs_g[1]);
@@ -445,11 +482,20 @@ void pgas_destroy(pgas_ctx* c) {
     delete c;
 }
 
+static int pack_params(pgas_ctx* c, const double* A_dev, const double* S_dev, hipStream_t st) {
+    c->tp.G = c->d_G;
+    HIPCHK(c, hipMemsetAsync(c->d_G, 0, c->gtotal * sizeof(double), st));
+    const int64_t n = (int64_t)c->md.M * c->md.nx;
+    hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A_dev, c->d_pos, c->md.M, c->md.nx, c->md.nrm, c->d_G, c->gtotal, c->tp, S_dev, c->d_tp);
+    KCHK(c, "k_pack");
+    c->have_params = true;
+    return PGAS_OK;
+}
+
 int pgas_set_params(pgas_ctx* c, const double* A_dev, const double* LS_host, const double* LSinv_host, double cS, void* stream) {
     if (!c) return PGAS_E_ARG;
     if (!A_dev || !LS_host || !LSinv_host) FAIL(c, PGAS_E_ARG, "pgas_set_params: NULL argument");
     DeviceGuard guard(c->device);
-    hipStream_t st = (hipStream_t)stream;
     const int nx = c->md.nx;
     for (int i = 0; i < 4; ++i) { c->tp.LS[i] = 0.0; c->tp.LSinv[i] = 0.0; }
     for (int k = 0; k < nx; ++k)
@@ -458,12 +504,30 @@ int pgas_set_params(pgas_ctx* c, const double* A_dev, const double* LS_host, con
             c->tp.LSinv[k * nx + l] = LSinv_host[k * nx + l];
         }
     c->tp.cS = cS;
-    c->tp.G = c->d_G;
-    HIPCHK(c, hipMemsetAsync(c->d_G, 0, c->gtotal * sizeof(double), st));
-    const int64_t n = (int64_t)c->md.M * nx;
-    hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A_dev, c->d_pos, c->md.M, nx, c->md.nrm, c->d_G, c->gtotal);
-    KCHK(c, "k_pack");
-    c->have_params = true;
+    return pack_params(c, A_dev, nullptr, (hipStream_t)stream);
+}
+
+/* The same with error_cov on the DEVICE (S_dev (nx,nx) row-major, symmetric positive definite): its Cholesky factor, the factor's
+ * inverse and the normalising constant are formed by the pack kernel itself, so a Gibbs iteration (sample_params -> sweep) involves
+ * no host round trip.  pgas_get_params reads back what the kernels will use (synchronises; tests). */
+int pgas_set_params_dev(pgas_ctx* c, const double* A_dev, const double* S_dev, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!A_dev || !S_dev) FAIL(c, PGAS_E_ARG, "pgas_set_params_dev: NULL argument");
+    DeviceGuard guard(c->device);
+    return pack_params(c, A_dev, S_dev, (hipStream_t)stream);
+}
+
+int pgas_get_params(pgas_ctx* c, double* LS_host, double* LSinv_host, double* cS, void* stream) {
+    if (!c) return PGAS_E_ARG;
+    if (!LS_host || !LSinv_host || !cS) FAIL(c, PGAS_E_ARG, "pgas_get_params: NULL argument");
+    if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_get_params: call pgas_set_params first");
+    DeviceGuard guard(c->device);
+    HIPCHK(c, hipStreamSynchronize((hipStream_t)stream));
+    TransParams tp;
+    HIPCHK(c, hipMemcpy(&tp, c->d_tp, sizeof tp, hipMemcpyDeviceToHost));
+    const int nx = c->md.nx;
+    for (int k = 0; k < nx * nx; ++k) { LS_host[k] = tp.LS[k]; LSinv_host[k] = tp.LSinv[k]; }
+    *cS = tp.cS;
     return PGAS_OK;
 }
 
@@ -482,7 +546,7 @@ int pgas_aux_states(pgas_ctx* c, const double* x_dev, int32_t t, double* aux_dev
     if (!x_dev || !aux_dev || t < 0 || t >= c->md.T) FAIL(c, PGAS_E_ARG, "pgas_aux_states: bad argument");
     if (!c->have_params) FAIL(c, PGAS_E_STATE, "pgas_aux_states: call pgas_set_params first");
     DeviceGuard guard(c->device);
-    hipLaunchKernelGGL(c->var.aux, dim3(c->md.nseg), dim3(PG_BLK), 0, (hipStream_t)stream, c->md, c->tp, t, x_dev, aux_dev);
+    hipLaunchKernelGGL(c->var.aux, dim3(c->md.nseg), dim3(PG_BLK), 0, (hipStream_t)stream, c->md, (const TransParams*)c->d_tp, t, x_dev, aux_dev);
     KCHK(c, "k_aux");
     return PGAS_OK;
 }
@@ -493,7 +557,7 @@ int pgas_init_state(pgas_ctx* c, uint64_t seed, const double* ref0_host, double*
     DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)stream;
     HIPCHK(c, hipMemcpyAsync(c->d_ref, ref0_host, c->md.nx * sizeof(double), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(c->init, dim3((c->md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, c->md, seed, c->d_m0L0, c->d_ref, x0_dev);
+    hipLaunchKernelGGL(c->init, dim3((c->md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, c->md, seed, (const SweepParams*)nullptr, c->d_m0L0, c->d_ref, x0_dev);
     KCHK(c, "k_init");
     return PGAS_OK;
 }
@@ -575,7 +639,8 @@ static int launch_groups(pgas_ctx* c, const ScanBufs& sb, int ncdf, hipStream_t 
 
 // what = 0: ancestor of the conditioned particle (step API), 1: final index
 static int launch_count(pgas_ctx* c, const ScanBufs& sb, int parity, int what, double u, hipStream_t st) {
-    hipLaunchKernelGGL(k_count, dim3(1), dim3(PG_BLK), 0, st, c->md.Ng, c->md.nseg_g, sb, peers_for(c, parity), what, u);
+    // what = 1 (final index of a sweep): the uniform is the running sweep's, read from the device (u is ignored)
+    hipLaunchKernelGGL(k_count, dim3(1), dim3(PG_BLK), 0, st, c->md.Ng, c->md.nseg_g, sb, peers_for(c, parity), what, u, what == 1 ? (const SweepParams*)c->d_sp : (const SweepParams*)nullptr);
     KCHK(c, "k_count");
     return PGAS_OK;
 }
@@ -592,15 +657,15 @@ static bool sweep_is_local(const pgas_ctx* c) { return c->local_groups && c->wor
 static bool sweep_tail_groups(const pgas_ctx* c) { return !c->sharded && c->world == 1 && c->tail_groups; }
 
 // launch t in [1, T] of the sweep: resamples step t-1 (t > 1), scans step t (t < T)
-static int launch_step(pgas_ctx* c, int t, uint64_t seed, bool local, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
+static int launch_step(pgas_ctx* c, int t, bool local, hipStream_t st, hipEvent_t e0, hipEvent_t e1) {
     const DevModel& md = c->md;
     const int N = md.N, T = md.T;
     StepArgs ar;
     ar.t = t;
     ar.mode = (t < T ? PG_RS_SCAN : 0) | (t > 1 ? PG_RS_SEARCH : 0);
-    ar.tag = ++c->launch_tag;
-    ar.u1_prev = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)(t - 1)) : 0.0;
-    ar.u2_prev = t > 1 ? pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)(t - 1)) : 0.0;
+    ar.sp = c->d_sp;
+    ar.u_res = c->d_ures;
+    ar.u_anc = c->d_uanc;
     ar.la_t = t < T ? (const double*)c->rs[PG_RB_LA].row(t) : (const double*)nullptr;
     ar.h_t = t < T ? (const double*)c->rs[PG_RB_H].row(t) : (const double*)nullptr;
     ar.ln_prev = (const double*)c->rs[PG_RB_LN].row(t - 1);
@@ -621,9 +686,10 @@ static int launch_step(pgas_ctx* c, int t, uint64_t seed, bool local, hipStream_
     const ScanBufs& sp = c->sb[(t - 1) & 1];
     const ScanBufs& sn = c->sb[t & 1];
     const Peers pr = peers_for(c, (t - 1) & 1);
-    if (local) hipExtLaunchKernelGGL((k_step<PG_WM_LOCAL, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
-    else if (sweep_tail_groups(c)) hipExtLaunchKernelGGL((k_step<PG_WM_GROUPS, true>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
-    else hipExtLaunchKernelGGL((k_step<PG_WM_GROUPS, false>), dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    auto kern = local ? k_step<PG_WM_LOCAL, false> : (sweep_tail_groups(c) ? k_step<PG_WM_GROUPS, true> : k_step<PG_WM_GROUPS, false>);
+    // dispatch-attached events only when this launch is timed: the plain launch is what a stream capture records
+    if (e0 || e1) hipExtLaunchKernelGGL(kern, dim3(md.nseg + 1), dim3(PG_BLK), 0, st, e0, e1, 0, md, ar, sp, sn, pr);
+    else hipLaunchKernelGGL(kern, dim3(md.nseg + 1), dim3(PG_BLK), 0, st, md, ar, sp, sn, pr);
     KCHK(c, "k_step");
     return PGAS_OK;
 }
@@ -641,7 +707,7 @@ int pgas_step(pgas_ctx* c, int32_t t, uint64_t seed, const double* logw_dev, con
     install_own_peers(c);
     HIPCHK(c, hipMemcpyAsync(c->d_ref, ref_t_host, md.nx * sizeof(double), hipMemcpyHostToDevice, st));
     if (c->corrected && !c->aux_buf) HIPCHK(c, hipMalloc(&c->aux_buf, (size_t)md.N * md.nx * sizeof(double)));
-    hipLaunchKernelGGL(c->var.front, dim3(md.nseg), dim3(PG_BLK), 0, st, md, c->tp, t, seed, x_dev, logw_dev, c->d_ref, c->corrected,
+    hipLaunchKernelGGL(c->var.front, dim3(md.nseg), dim3(PG_BLK), 0, st, md, (const TransParams*)c->d_tp, t, seed, x_dev, logw_dev, c->d_ref, c->corrected,
                        c->corrected ? c->aux_buf : x_new_dev, c->sb[0]);
     KCHK(c, "k_front");
     int rc = launch_groups(c, c->sb[0], 2, st);
@@ -650,7 +716,7 @@ int pgas_step(pgas_ctx* c, int32_t t, uint64_t seed, const double* logw_dev, con
     if (rc) return rc;
     const Peers pr = peers_for(c, 0);
     if (c->corrected) {
-        hipLaunchKernelGGL(c->back_corrected, dim3(md.nseg), dim3(PG_BLK), 0, st, md, c->tp, t, seed,
+        hipLaunchKernelGGL(c->back_corrected, dim3(md.nseg), dim3(PG_BLK), 0, st, md, (const TransParams*)c->d_tp, t, seed,
                            pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t), c->aux_buf, c->d_ref, c->sb[0], pr, anc_dev, x_new_dev, logw_new_dev);
     } else {
         hipLaunchKernelGGL(c->back, dim3(md.nseg), dim3(PG_BLK), 0, st, md, t,
@@ -709,7 +775,7 @@ static int ensure_traces(pgas_ctx* c, bool blocked) {
 }
 
 // k_propagate for time steps [t0, t1), optionally carrying dispatch-attached events
-static int launch_propagate(pgas_ctx* c, uint64_t seed, int t0, int t1, const double* ref_dev, hipStream_t st, bool timed) {
+static int launch_propagate(pgas_ctx* c, int t0, int t1, const double* ref_dev, hipStream_t st, bool timed) {
     const int spw = c->var.PPT / PG_PPT;   // segments per k_propagate workgroup
     const dim3 grid((c->md.nseg + spw - 1) / spw), blk(PG_BLK);
     size_t lds = c->overlap ? c->prop_lds : 0;
@@ -736,11 +802,11 @@ static int launch_propagate(pgas_ctx* c, uint64_t seed, int t0, int t1, const do
                 c->evp.push_back(e);
             }
             // start/stop events bound to the dispatch itself: they carry the kernel's own begin/end timestamps
-            hipExtLaunchKernelGGL(prop, grid, blk, lds, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, c->md, c->tp, seed, ta, tb, x_prev, x_rows,
-                                  ref_dev, la, h, ln);
+            hipExtLaunchKernelGGL(prop, grid, blk, lds, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, c->md, (const TransParams*)c->d_tp,
+                                  (const double*)c->d_G, (const SweepParams*)c->d_sp, ta, tb, x_prev, x_rows, ref_dev, la, h, ln);
             c->evp_used += 2;
         } else {
-            hipLaunchKernelGGL(prop, grid, blk, lds, st, c->md, c->tp, seed, ta, tb, x_prev, x_rows, ref_dev, la, h, ln);
+            hipLaunchKernelGGL(prop, grid, blk, lds, st, c->md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp, ta, tb, x_prev, x_rows, ref_dev, la, h, ln);
         }
         KCHK(c, "k_propagate");
         ta = tb;
@@ -771,9 +837,17 @@ static int ensure_side_stream(pgas_ctx* c, int nchunk) {
 // (both arrays in one group, on the sweep's stream); a host callback when the caller installed one (tests on one device).
 static int shard_all_gather(pgas_ctx* c, int parity, hipStream_t st);
 
+// seed, epoch and the T + 1 resampling / ancestor uniforms of a new sweep into device memory (what its kernels read them from)
+static int sweep_begin(pgas_ctx* c, uint64_t seed, hipStream_t st) {
+    ++c->epoch;
+    hipLaunchKernelGGL(k_sweep_begin, dim3((unsigned)((c->md.T + 1 + 255) / 256)), dim3(256), 0, st, seed, c->epoch, c->md.T, c->d_sp, c->d_ures, c->d_uanc);
+    KCHK(c, "k_sweep_begin");
+    return PGAS_OK;
+}
+
 // The time loop shared by pgas_sweep and pgas_shard_sweep: pipeline A (k_propagate, caller's stream) runs ahead chunk by chunk,
 // pipeline B (k_step [+ all-gather + k_groups]) follows on the internal stream, gated by one event per chunk.
-static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int chunk, hipStream_t st) {
+static int run_time_loop(pgas_ctx* c, const double* ref_dev, int chunk, hipStream_t st) {
     const DevModel& md = c->md;
     const int T = md.T;
     const bool local = sweep_is_local(c);
@@ -811,7 +885,7 @@ static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int 
         if (lead > 0 && gi >= lead) HIPCHK(c, hipStreamWaitEvent(st, c->ev_bdone[gi - lead], 0));
         for (int ci = c0; ci < c1; ++ci) {
             const int t0 = 1 + ci * chunk, t1 = t0 + chunk < T ? t0 + chunk : T;
-            int rc = launch_propagate(c, seed, t0, t1, ref_dev, st, c->profiling && (ci % c->prof_stride) == 0);
+            int rc = launch_propagate(c, t0, t1, ref_dev, st, c->profiling && (ci % c->prof_stride) == 0);
             if (rc) return rc;
         }
         if (sB != st) {
@@ -825,7 +899,7 @@ static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int 
             const bool timed = c->profiling && t < T && (t % c->prof_stride) == 0;
             hipEvent_t e0 = timed ? c->ev[c->ev_used] : (hipEvent_t) nullptr, e1 = timed ? c->ev[c->ev_used + 1] : (hipEvent_t) nullptr;
             if (timed) c->ev_used += 2;
-            int rc = launch_step(c, t, seed, local, sB, e0, e1);
+            int rc = launch_step(c, t, local, sB, e0, e1);
             if (rc) return rc;
             if (!local && t < T && !sweep_tail_groups(c)) {
                 if (c->sharded) {
@@ -846,7 +920,7 @@ static int run_time_loop(pgas_ctx* c, uint64_t seed, const double* ref_dev, int 
 }
 
 // final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
-static int run_final(pgas_ctx* c, uint64_t seed, double* traj_dev, hipStream_t st) {
+static int run_final(pgas_ctx* c, double* traj_dev, hipStream_t st) {
     const DevModel& md = c->md;
     const int T = md.T;
     const ScanBufs& sf = c->sb[T & 1];
@@ -859,9 +933,74 @@ static int run_final(pgas_ctx* c, uint64_t seed, double* traj_dev, hipStream_t s
     }
     rc = launch_groups(c, sf, 1, st);
     if (rc) return rc;
-    rc = launch_count(c, sf, T & 1, 1, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), st);
+    rc = launch_count(c, sf, T & 1, 1, 0.0, st);
     if (rc) return rc;
     return launch_backtrace(c, sf.hdr, traj_dev, st);
+}
+
+// everything of a default-mode sweep after sweep_begin: x_0, the time loop, the final index and the back-trace
+static int sweep_body(pgas_ctx* c, const double* ref_dev, double* traj_dev, int chunk, hipStream_t st) {
+    const DevModel& md = c->md;
+    hipLaunchKernelGGL(c->init, dim3((md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, md, (uint64_t)0, (const SweepParams*)c->d_sp, c->d_m0L0, ref_dev,
+                       (double*)c->rs[PG_RB_X].row(0));
+    KCHK(c, "k_init");
+    if (md.T == 1) {
+        HIPCHK(c, hipMemsetAsync(c->logw_last, 0, md.N * sizeof(double), st));
+    } else {
+        int rc = run_time_loop(c, ref_dev, chunk, st);
+        if (rc) return rc;
+        if (c->logw_trace)
+            HIPCHK(c, hipMemcpyAsync(c->logw_trace + (size_t)(md.T - 1) * md.N, c->logw_last, md.N * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    return run_final(c, traj_dev, st);
+}
+
+// Capture sweep_body once (reference trajectory and result in the library's own buffers) and keep the instantiated graph; any
+// failure leaves the context on the eager path for good.  Returns true when c->graph_exec is ready for `key`.
+static bool sweep_graph_ready(pgas_ctx* c, const int (&key)[6], int chunk) {
+    if (c->graph_failed) return false;
+    bool same = c->graph_exec != nullptr;
+    for (int i = 0; i < 6; ++i) same = same && c->graph_key[i] == key[i];
+    if (same) return true;
+    auto give_up = [&](const char* what, hipError_t e) {
+        const char* dbg = getenv("PGAS_GRAPH_DEBUG");
+        if (dbg && dbg[0] == '1') fprintf(stderr, "pgas: sweep graph disabled: %s: %s\n", what, hipGetErrorString(e));
+        (void)hipGetLastError();
+        c->graph_failed = 1;
+        return false;
+    };
+    if (c->graph_exec) { (void)hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+    if (c->graph) { (void)hipGraphDestroy(c->graph); c->graph = nullptr; }
+    hipError_t e = hipSuccess;
+    if (!c->sG) {
+        e = hipStreamCreateWithFlags(&c->sG, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_g0, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_g1, hipEventDisableTiming);
+        if (e != hipSuccess) return give_up("stream / event creation", e);
+    }
+    // nothing that allocates or synchronises may run inside the capture: side stream, events and the back-trace table first
+    const int nchunk = c->md.T > 1 ? (c->md.T - 1 + chunk - 1) / chunk : 1;
+    BtTab tab;
+    if ((c->overlap && ensure_side_stream(c, nchunk)) || upload_bt_table(c, c->sG, &tab)) return give_up("set-up before the capture", hipErrorUnknown);
+    e = hipStreamBeginCapture(c->sG, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) return give_up("hipStreamBeginCapture", e);
+    const int rc = sweep_body(c, c->d_refbuf, c->d_trajbuf, chunk, c->sG);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(c->sG, &g);
+    if (rc || e != hipSuccess || !g) {
+        if (g) (void)hipGraphDestroy(g);
+        return give_up(rc ? c->err.c_str() : "hipStreamEndCapture", e);
+    }
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (e != hipSuccess || !ex) {
+        (void)hipGraphDestroy(g);
+        return give_up("hipGraphInstantiate", e);
+    }
+    c->graph = g;
+    c->graph_exec = ex;
+    for (int i = 0; i < 6; ++i) c->graph_key[i] = key[i];
+    return true;
 }
 
 int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_dev, void* stream) {
@@ -878,45 +1017,61 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
     const size_t row = (size_t)N * nx;
     const dim3 grid(md.nseg), blk(PG_BLK);
     auto xrow = [&](int t) { return (double*)c->rs[PG_RB_X].row(t); };
-
-    hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, xrow(0));
-    KCHK(c, "k_init");
     c->ev_used = 0;
     c->evp_used = 0;
-    if (T == 1) {
-        HIPCHK(c, hipMemsetAsync(c->logw_last, 0, N * sizeof(double), st));
-    } else if (c->corrected) {
+    if (c->corrected && T > 1) {
         // corrected mode: x_t depends on the ancestors a_t, so the step is a serial chain on one stream
         // (transition means + scans, group scans, reference ancestor, search + propagate + weights)
+        rc = sweep_begin(c, seed, st);   // final-index uniform
+        if (rc) return rc;
+        hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, (const SweepParams*)nullptr, c->d_m0L0, ref_dev, xrow(0));
+        KCHK(c, "k_init");
         if (!c->aux_buf) HIPCHK(c, hipMalloc(&c->aux_buf, row * sizeof(double)));
         const Peers pr = peers_for(c, 0);
         for (int t = 1; t < T; ++t) {
             const double* lw_prev = t == 1 ? (const double*)nullptr : (c->logw_trace ? c->logw_trace + (size_t)(t - 1) * N : c->logw_last);
             double* lw_out = c->logw_trace ? c->logw_trace + (size_t)t * N : c->logw_last;
-            hipLaunchKernelGGL(c->var.front, grid, blk, 0, st, md, c->tp, t, seed, xrow(t - 1), lw_prev, ref_dev + (size_t)t * nx, 1,
+            hipLaunchKernelGGL(c->var.front, grid, blk, 0, st, md, (const TransParams*)c->d_tp, t, seed, xrow(t - 1), lw_prev, ref_dev + (size_t)t * nx, 1,
                                c->aux_buf, c->sb[0]);
             KCHK(c, "k_front");
             rc = launch_groups(c, c->sb[0], 2, st);
             if (rc) return rc;
             rc = launch_count(c, c->sb[0], 0, 0, pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t), st);
             if (rc) return rc;
-            hipLaunchKernelGGL(c->back_corrected, grid, blk, 0, st, md, c->tp, t, seed, pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t),
+            hipLaunchKernelGGL(c->back_corrected, grid, blk, 0, st, md, (const TransParams*)c->d_tp, t, seed, pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t),
                                c->aux_buf, ref_dev + (size_t)t * nx, c->sb[0], pr, (int32_t*)c->rs[PG_RB_ANC].row(t - 1), xrow(t), lw_out);
             KCHK(c, "k_back_corrected");
         }
         if (c->logw_trace)
             HIPCHK(c, hipMemcpyAsync(c->logw_last, c->logw_trace + (size_t)(T - 1) * N, N * sizeof(double), hipMemcpyDeviceToDevice, st));
-    } else {
-        // default chunk, measured (tools/ab_bench.py --chunk, tools/config_times.py): one step per k_propagate launch for the cheap 1-D / 2-D
-        // bases, 16 for the 3-D bases whose k_propagate launches are ten times longer than a k_step launch
-        const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 1 : T);
-        c->last_chunk = chunk;
-        rc = run_time_loop(c, seed, ref_dev, chunk, st);
-        if (rc) return rc;
-        if (c->logw_trace)
-            HIPCHK(c, hipMemcpyAsync(c->logw_trace + (size_t)(T - 1) * N, c->logw_last, N * sizeof(double), hipMemcpyDeviceToDevice, st));
+        return run_final(c, traj_dev, st);
     }
-    return run_final(c, seed, traj_dev, st);
+    // default chunk, measured (tools/ab_bench.py --chunk, tools/config_times.py): one step per k_propagate launch
+    const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 1 : T);
+    c->last_chunk = chunk;
+    // PGAS_OPT_GRAPH (default on): the ~6000 launches of a sweep are captured once and replayed; launches that carry timing events
+    // (pgas_set_profiling) and the development knobs that wait across streams stay on the eager path
+    const int key[6] = {chunk, c->overlap, c->ev_stride, sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0), c->prop_lds, c->keep_logw};
+    c->last_graph = 0;
+    const bool want_graph = c->use_graph == 1 || (c->use_graph < 0 && md.N <= PG_GRAPH_AUTO_N);
+    if (want_graph && !c->profiling && c->max_lead == 0 && sweep_graph_ready(c, key, chunk)) {
+        // the replay runs on the library's own stream, behind everything the caller has enqueued and in front of what it enqueues next
+        const size_t nb = (size_t)T * nx * sizeof(double);
+        HIPCHK(c, hipEventRecord(c->ev_g0, st));
+        HIPCHK(c, hipStreamWaitEvent(c->sG, c->ev_g0, 0));
+        rc = sweep_begin(c, seed, c->sG);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(c->d_refbuf, ref_dev, nb, hipMemcpyDeviceToDevice, c->sG));
+        HIPCHK(c, hipGraphLaunch(c->graph_exec, c->sG));
+        HIPCHK(c, hipMemcpyAsync(traj_dev, c->d_trajbuf, nb, hipMemcpyDeviceToDevice, c->sG));
+        HIPCHK(c, hipEventRecord(c->ev_g1, c->sG));
+        HIPCHK(c, hipStreamWaitEvent(st, c->ev_g1, 0));
+        c->last_graph = 1;
+        return PGAS_OK;
+    }
+    rc = sweep_begin(c, seed, st);
+    if (rc) return rc;
+    return sweep_body(c, ref_dev, traj_dev, chunk, st);
 }
 
 int pgas_get_traces(pgas_ctx* c, double** x_trace, int32_t** anc_trace, double** logw_last, double** logw_trace) {
@@ -1017,6 +1172,10 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         c->prop_lds = (int)value;
         return PGAS_OK;
     }
+    if (option == PGAS_OPT_GRAPH) {
+        c->use_graph = value ? 1 : 0;
+        return PGAS_OK;
+    }
     if (option == PGAS_OPT_TRACE_BLOCK_BYTES) {
         if (value < 0) FAIL(c, PGAS_E_ARG, "pgas_set_option: block bytes must be >= 0");
         if (c->have_traces) FAIL(c, PGAS_E_STATE, "pgas_set_option: the traces are already allocated");
@@ -1067,7 +1226,7 @@ int pgas_get_launch_info(pgas_ctx* c, int32_t* info4) {
     if (!c) return PGAS_E_ARG;
     if (!info4) FAIL(c, PGAS_E_ARG, "pgas_get_launch_info: NULL argument");
     info4[0] = c->last_chunk;
-    info4[1] = sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0);
+    info4[1] = (sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0)) + (c->last_graph ? 16 : 0);   // + 16: the last sweep replayed the captured graph
     info4[2] = c->md.JP;
     info4[3] = c->var_P;
     return PGAS_OK;
@@ -1291,15 +1450,17 @@ int pgas_shard_run(pgas_ctx* c, int32_t phase, int32_t t, int32_t t_aux, uint64_
     switch (phase) {
     case PGAS_SHARD_INIT:
         if (!ref_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_run(INIT): ref_dev == NULL");
-        hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].row(0));
+        rc = sweep_begin(c, seed, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(c->init, dim3((N + PG_BLK - 1) / PG_BLK), blk, 0, st, md, seed, (const SweepParams*)nullptr, c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].row(0));
         KCHK(c, "k_init");
         return PGAS_OK;
     case PGAS_SHARD_PROPAGATE:  // time steps [t, t_aux)
         if (!ref_dev || t < 1 || t_aux > T || t >= t_aux) FAIL(c, PGAS_E_ARG, "pgas_shard_run(PROPAGATE): bad range [%d,%d)", t, t_aux);
-        return launch_propagate(c, seed, t, t_aux, ref_dev, st, false);
+        return launch_propagate(c, t, t_aux, ref_dev, st, false);
     case PGAS_SHARD_STEP:  // launch t in [1, T]: resample step t-1 (t > 1), scan step t (t < T)
         if (t < 1 || t > T) FAIL(c, PGAS_E_ARG, "pgas_shard_run(STEP): t = %d outside [1, %d]", t, T);
-        return launch_step(c, t, seed, false, st, nullptr, nullptr);
+        return launch_step(c, t, false, st, nullptr, nullptr);
     case PGAS_SHARD_GROUPS:  // after the all-gather of step t's partials
         if (t < 1 || t >= T) FAIL(c, PGAS_E_ARG, "pgas_shard_run(GROUPS): t = %d outside [1, %d)", t, T);
         return launch_groups(c, c->sb[t & 1], 2, st);
@@ -1310,7 +1471,7 @@ int pgas_shard_run(pgas_ctx* c, int32_t phase, int32_t t, int32_t t_aux, uint64_
     case PGAS_SHARD_FINAL:  // after the all-gather of the final scan's partials: final index (src/PGAS.py:224-225)
         rc = launch_groups(c, c->sb[T & 1], 1, st);
         if (rc) return rc;
-        return launch_count(c, c->sb[T & 1], T & 1, 1, pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u), st);
+        return launch_count(c, c->sb[T & 1], T & 1, 1, 0.0, st);
     case PGAS_SHARD_BACKTRACE:
         if (!traj_dev) FAIL(c, PGAS_E_ARG, "pgas_shard_run(BACKTRACE): traj_dev == NULL");
         return launch_backtrace(c, c->sb[T & 1].hdr, traj_dev, st);
@@ -1385,7 +1546,9 @@ int pgas_shard_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* 
     hipStream_t st = (hipStream_t)stream;
     const DevModel& md = c->md;
     const int T = md.T;
-    hipLaunchKernelGGL(c->init, dim3((md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, md, seed, c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].row(0));
+    rc = sweep_begin(c, seed, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(c->init, dim3((md.N + PG_BLK - 1) / PG_BLK), dim3(PG_BLK), 0, st, md, seed, (const SweepParams*)nullptr, c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].row(0));
     KCHK(c, "k_init");
     c->ev_used = 0;
     c->evp_used = 0;
@@ -1394,10 +1557,10 @@ int pgas_shard_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* 
     } else {
         const int chunk = propagate_chunk > 0 ? propagate_chunk : (c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 1 : T));
         c->last_chunk = chunk;
-        rc = run_time_loop(c, seed, ref_dev, chunk, st);
+        rc = run_time_loop(c, ref_dev, chunk, st);
         if (rc) return rc;
     }
-    rc = run_final(c, seed, traj_dev, st);
+    rc = run_final(c, traj_dev, st);
     if (rc) return rc;
     // peers may still be chasing ancestors through this rank's traces: one more (tiny) collective closes the sweep on every rank
     return shard_all_gather(c, -1, st);

@@ -70,6 +70,12 @@ __device__ __forceinline__ T ld_stream(const T* p) {
 #endif
 }
 
+// load through the constant address space: for memory nothing writes while the kernel runs (device-resident parameters)
+template <typename T>
+__device__ __forceinline__ T ld_const(const T* p) {
+    return *(const __attribute__((address_space(4))) T*)p;
+}
+
 struct DevModel {
     int32_t N, T, nx, ny, nu, D, M;
     int32_t J[PGAS_MAX_D], j0[PGAS_MAX_D], jstep[PGAS_MAX_D], sel[PGAS_MAX_D];
@@ -92,9 +98,21 @@ struct DevModel {
                             // can skip (exact: adding 0 * s changes nothing)
 };
 
-struct TransParams {   // transition parameters, by value
+struct TransParams {   // transition parameters; ONE copy lives in device memory (pgas_ctx::d_tp) and every kernel reads it from there, so
+                       // that a captured sweep (HIP graph) picks up new parameters on replay and pgas_set_params_dev can produce
+                       // them without a host round trip
     double LS[4], LSinv[4], cS;
     const double* G;   // packed coefficient tensor
+};
+
+#define PGAS_LOG_2PI 0x1.d67f1c864beb4p+0   /* log(2 pi) rounded to nearest */
+
+struct SweepParams {   // device-resident per-sweep scalars, written by k_sweep_begin before the time loop: the kernels of a sweep take
+                       // nothing seed-dependent by value, so the whole sweep can be captured once in a HIP graph and replayed
+    uint64_t seed;
+    uint32_t epoch;    // sweeps run on this context so far: makes the ancestor hand-off tag of launch t unique across replays
+    uint32_t pad;
+    double u_final;    // uniform of the final index (src/PGAS.py:225)
 };
 
 struct UpperHdr {      // small per-scan-buffer results
@@ -564,7 +582,7 @@ __device__ __forceinline__ void dim_sines_point(const DevModel& md, int d, const
 // k_pack: G[pos[m]][k] = A[k][m] * nrm, zero elsewhere
 // ------------------------------------------------------------------------------------------
 __global__ void k_pack(const double* __restrict__ A, const int32_t* __restrict__ pos, int M, int nx, double nrm,
-                       double* __restrict__ G, int64_t gtotal) {
+                       double* __restrict__ G, int64_t gtotal, TransParams tp_host, const double* __restrict__ S_dev, TransParams* __restrict__ tp_out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     // phase split by launch: caller memsets G first
     if (i < (int64_t)M * nx) {
@@ -572,16 +590,59 @@ __global__ void k_pack(const double* __restrict__ A, const int32_t* __restrict__
         G[(int64_t)pos[m] * nx + k] = A[(int64_t)k * M + m] * nrm;
     }
     (void)gtotal;
+    if (i == 0) {
+        TransParams tp = tp_host;   // pgas_set_params: factor, inverse and constant computed by the caller
+        if (S_dev != nullptr) {
+            // pgas_set_params_dev: error_cov (nx, nx) is on the device; its Cholesky factor, the factor's inverse and the normalising
+            // constant in IEEE operations only (sqrt, /, *, -, pgas_log), in this order -- oracle/canon.py chol_parts_dev mirrors it
+            for (int q = 0; q < 4; ++q) tp.LS[q] = 0.0, tp.LSinv[q] = 0.0;
+            if (nx == 1) {
+                const double l = __builtin_sqrt(S_dev[0]);
+                tp.LS[0] = l;
+                tp.LSinv[0] = 1.0 / l;
+                tp.cS = -0.5 * PGAS_LOG_2PI - pgas_log(l);
+            } else {
+                const double l00 = __builtin_sqrt(S_dev[0]);
+                const double l10 = S_dev[2] / l00;
+                const double l11 = __builtin_sqrt(S_dev[3] - l10 * l10);
+                const double i00 = 1.0 / l00, i11 = 1.0 / l11;
+                tp.LS[0] = l00; tp.LS[2] = l10; tp.LS[3] = l11;
+                tp.LSinv[0] = i00; tp.LSinv[2] = -(l10 * i00) * i11; tp.LSinv[3] = i11;
+                tp.cS = -PGAS_LOG_2PI - (pgas_log(l00) + pgas_log(l11));
+            }
+        }
+        *tp_out = tp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep_begin: the sweep's scalars and its T + 1 resampling / ancestor uniforms (src/Filtering.py:19, src/PGAS.py:123) into device memory
+// ------------------------------------------------------------------------------------------
+__global__ void k_sweep_begin(uint64_t seed, uint32_t epoch, int T, SweepParams* __restrict__ sp, double* __restrict__ u_res,
+                              double* __restrict__ u_anc) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t <= T) {
+        u_res[t] = pgas_rng_uniform(seed, PGAS_STREAM_RESAMPLE, (uint32_t)t);
+        u_anc[t] = pgas_rng_uniform(seed, PGAS_STREAM_ANCESTOR, (uint32_t)t);
+    }
+    if (t == 0) {
+        sp->seed = seed;
+        sp->epoch = epoch;
+        sp->pad = 0;
+        sp->u_final = pgas_rng_uniform(seed, PGAS_STREAM_FINAL, 0u);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_init: x_0 = m0 + L0 z, conditioned particle last
 // ------------------------------------------------------------------------------------------
 template <int NX>
-__global__ __launch_bounds__(PG_BLK) void k_init(DevModel md, uint64_t seed, const double* __restrict__ m0L0 /* m0[nx], L0[nx*nx] */,
+__global__ __launch_bounds__(PG_BLK) void k_init(DevModel md, uint64_t seed_val, const SweepParams* __restrict__ sp /* non-NULL: seed from there */,
+                                                  const double* __restrict__ m0L0 /* m0[nx], L0[nx*nx] */,
                                                   const double* __restrict__ ref0, double* __restrict__ x0) {
     const int64_t p = (int64_t)blockIdx.x * PG_BLK + threadIdx.x;
     if (p >= md.N) return;
+    const uint64_t seed = sp ? sp->seed : seed_val;
     double z[2];
     pgas_rng_normals(seed, PGAS_STREAM_INIT, 0u, (uint64_t)(md.p0 + p), NX, z);
     double xv[NX];
@@ -863,10 +924,11 @@ __device__ __forceinline__ void load_particles(const DevModel& md, const double*
 
 // k_front: one workgroup per segment.
 template <int NX, int D, int JIN, int P>
-__global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, TransParams tp, int t, uint64_t seed,
+__global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, const TransParams* __restrict__ tpp, int t, uint64_t seed,
                                                    const double* __restrict__ x_prev, const double* __restrict__ logw_prev,
                                                    const double* __restrict__ ref_t, int corrected, double* __restrict__ x_new, ScanBufs sb) {
     __shared__ ScanSmem sm;
+    const TransParams tp = *tpp;
     const int seg = blockIdx.x, tid = threadIdx.x;
     double xv[PG_PPT][NX], lwp[PG_PPT], lw[2][PG_PPT];
     load_particles<NX>(md, x_prev, seg, xv);
@@ -939,13 +1001,26 @@ __device__ __forceinline__ void propagate_group(const DevModel& md, const TransP
 // at once) beats 4 by 6-9 % when the weight recursion runs beside it.
 // ONE = the launch covers exactly one time step (t1 == t0 + 1; what the sweep uses for the cheap bases): a group's state is then
 // loaded right before its pass instead of being held for the whole launch (8 particles x 2 doubles = 32 VGPRs less).
-template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT, bool ONE = false>
-__global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParams tp, uint64_t seed, int t0, int t1,
-                                                          const double* __restrict__ x_prev /* row t0-1 */, double* __restrict__ x_rows /* rows t0 ... */,
-                                                          const double* __restrict__ ref,
-                                                          double* __restrict__ la_rows, double* __restrict__ h_rows,
-                                                          double* __restrict__ ln_rows /* rows t0 ... of the hand-off buffers */) {
+template <int NX, int D, int JIN, int P, int J0T, int PPT, bool ONE>
+__device__ __forceinline__ void propagate_kernel(const DevModel& md, const TransParams* __restrict__ tpp, const double* __restrict__ G_arg, const SweepParams* __restrict__ swp, int t0, int t1,
+                                                 const double* __restrict__ x_prev /* row t0-1 */, double* __restrict__ x_rows /* rows t0 ... */,
+                                                 const double* __restrict__ ref,
+                                                 double* __restrict__ la_rows, double* __restrict__ h_rows,
+                                                 double* __restrict__ ln_rows /* rows t0 ... of the hand-off buffers */) {
     const int tid = threadIdx.x;
+    // Device-resident parameters (a replayed graph sees the current ones), read through the constant address space: nothing writes them
+    // while the kernel runs.  The coefficient tensor's ADDRESS stays a kernel argument: taken from memory (tp.G), the tensor's scalar
+    // loads lose their kernarg provenance and the schedule of this kernel went from 140 to 193 registers -- one k_step wave per SIMD
+    // beside it instead of two, 83 instead of 69 ms per sweep.
+    TransParams tp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        tp.LS[q] = ld_const(&tpp->LS[q]);
+        tp.LSinv[q] = ld_const(&tpp->LSinv[q]);
+    }
+    tp.cS = ld_const(&tpp->cS);
+    tp.G = G_arg;
+    const uint64_t seed = ld_const(&swp->seed);
     const size_t row = (size_t)md.N * NX, np = (size_t)md.nseg * PGAS_SEG;
     // 3-D bases: the coefficient tensor (J0 x J1 x JIN x NX doubles, 23 KB for the 729-function bases) is copied to LDS once per launch
     // and read from there with wave-uniform (broadcast) addresses: per row of the frequency grid the scalar-load path would stall
@@ -1052,6 +1127,12 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, TransParam
     }
 }
 
+template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT, bool ONE = false>
+__global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, const TransParams* __restrict__ tpp, const double* __restrict__ G, const SweepParams* __restrict__ swp, int t0, int t1,
+                                                          const double* __restrict__ x_prev, double* __restrict__ x_rows, const double* __restrict__ ref,
+                                                          double* __restrict__ la_rows, double* __restrict__ h_rows, double* __restrict__ ln_rows) {
+    propagate_kernel<NX, D, JIN, P, J0T, PPT, ONE>(md, tpp, G, swp, t0, t1, x_prev, x_rows, ref, la_rows, h_rows, ln_rows);
+}
 // ------------------------------------------------------------------------------------------
 // k_segscan: softmax scan of a plain weight vector (final index draw, src/PGAS.py:224)
 // ------------------------------------------------------------------------------------------
@@ -1118,8 +1199,9 @@ __global__ __launch_bounds__(PG_BLK) void k_basis_eval(DevModel md, const int32_
 }
 
 template <int NX, int D, int JIN, int P>
-__global__ __launch_bounds__(PG_BLK) void k_aux(DevModel md, TransParams tp, int t, const double* __restrict__ x, double* __restrict__ aux_out) {
+__global__ __launch_bounds__(PG_BLK) void k_aux(DevModel md, const TransParams* __restrict__ tpp, int t, const double* __restrict__ x, double* __restrict__ aux_out) {
     const int seg = blockIdx.x, tid = threadIdx.x;
+    const TransParams tp = *tpp;
     double xv[PG_PPT][NX];
     load_particles<NX>(md, x, seg, xv);
     const double* __restrict__ ut = md.u + (size_t)t * md.nu;

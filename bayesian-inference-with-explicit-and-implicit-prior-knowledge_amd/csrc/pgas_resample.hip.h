@@ -706,9 +706,10 @@ __device__ __forceinline__ int cdf_count_wg(WinSmemT<LOCAL>& sm, const ScanBufs&
 
 // k_count: one workgroup; what = 0: reference ancestor of pgas_step (CDF 1 against c2) -> hdr->ref_idx,
 //                          what = 1: final index (CDF 0 against c1)                    -> hdr->final_idx
-__global__ __launch_bounds__(PG_BLK) void k_count(int N, int nseg, ScanBufs sb, Peers pr, int what, double u) {
+__global__ __launch_bounds__(PG_BLK) void k_count(int N, int nseg, ScanBufs sb, Peers pr, int what, double u_val, const SweepParams* __restrict__ sp) {
     __shared__ WinSmemT<PG_WM_GROUPS> sm;
     const int cdf = what == 0 ? 1 : 0;
+    const double u = sp ? sp->u_final : u_val;   // sweeps: the final-index uniform of the running sweep, device-resident
     const int r = cdf_count_wg<PG_WM_GROUPS>(sm, sb, pr, cdf, nseg, N, u, cdf ? sb.c2 : sb.c1, cdf ? pr.c2 : pr.c1, nullptr);
     if (threadIdx.x == 0) {
         if (what == 0) sb.hdr->ref_idx = r; else sb.hdr->final_idx = r;
@@ -741,10 +742,11 @@ __global__ __launch_bounds__(PG_BLK) void k_back(DevModel md, int t, double u1, 
 // aux holds the transition means k_front stored; the noise z_i is the same Philox draw the default mode uses for
 // particle i at time t, so the two modes differ only in which mean the noise is added to.
 template <int NX>
-__global__ __launch_bounds__(PG_BLK) void k_back_corrected(DevModel md, TransParams tp, int t, uint64_t seed, double u1,
+__global__ __launch_bounds__(PG_BLK) void k_back_corrected(DevModel md, const TransParams* __restrict__ tpp, int t, uint64_t seed, double u1,
                                                             const double* __restrict__ aux, const double* __restrict__ ref_t, ScanBufs sb, Peers pr,
                                                             int32_t* __restrict__ anc_out, double* __restrict__ x_new,
                                                             double* __restrict__ logw_out) {
+    const TransParams tp = *tpp;
     __shared__ WinSmemT<PG_WM_GROUPS> sm;
     const int seg = blockIdx.x, tid = threadIdx.x;
     int anc[PG_PPT];
@@ -802,8 +804,9 @@ __global__ __launch_bounds__(PG_BLK) void k_systematic(DevModel md, double u, co
 
 struct StepArgs {
     int t, mode;
-    unsigned tag;
-    double u1_prev, u2_prev;
+    const SweepParams* sp;   // epoch (hand-off tag) of the running sweep
+    const double* u_res;     // (T + 1) resampling uniforms of the sweep, device (k_sweep_begin); launch t searches with u_res[t-1]
+    const double* u_anc;     // (T + 1) ancestor uniforms; the ancestor workgroup of launch t draws with u_anc[t-1]
     const double* la_t;      // (np) row t of la_buf, this device
     const double* h_t;       // (np) row t of h_buf
     const double* ln_prev;   // (np) row t-1 of ln_buf
@@ -831,14 +834,18 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
     __shared__ WinSmemT<LOCAL> sm;
     const int tid = threadIdx.x;
     const int N = md.N;
+    // unique per launch and per sweep (replays of a captured sweep included): 2654435761 is odd, so two launches collide only if their
+    // step numbers differ by a multiple of it
+    const unsigned tag = ar.sp->epoch * 2654435761u + (unsigned)ar.t;
+    const double u1_prev = (ar.mode & PG_RS_SEARCH) ? ar.u_res[ar.t - 1] : 0.0, u2_prev = (ar.mode & PG_RS_SEARCH) ? ar.u_anc[ar.t - 1] : 0.0;
 #ifdef PG_STEP_PRIO
     __builtin_amdgcn_s_setprio(PG_STEP_PRIO);   // the weight recursion is the latency chain of the sweep: let its few vector instructions go first
 #endif
     if (blockIdx.x == 0) {  // ---- ancestor workgroup
         if (!(ar.mode & PG_RS_SEARCH)) return;
-        const int r = cdf_count_wg<LOCAL>(sm, sb_prev, pr, 1, md.nseg_g, md.Ng, ar.u2_prev, nullptr, nullptr, &ar.anc_in);
+        const int r = cdf_count_wg<LOCAL>(sm, sb_prev, pr, 1, md.nseg_g, md.Ng, u2_prev, nullptr, nullptr, &ar.anc_in);
         if (tid == 0)
-            __hip_atomic_store(&sb_prev.hdr->ref_granule, ((unsigned long long)ar.tag << 32) | (unsigned)r, __ATOMIC_RELAXED,
+            __hip_atomic_store(&sb_prev.hdr->ref_granule, ((unsigned long long)tag << 32) | (unsigned)r, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
@@ -852,7 +859,7 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
     double lwp[PG_PPT] = {0.0, 0.0, 0.0, 0.0};
     if (ar.mode & PG_RS_SEARCH) {
         int a[PG_PPT];
-        resample_search<LOCAL>(md, sm, ar.u1_prev, sb_prev, pr, seg, a, [&]() {
+        resample_search<LOCAL>(md, sm, u1_prev, sb_prev, pr, seg, a, [&]() {
 #pragma unroll
             for (int r = 0; r < PG_PPT; ++r) lnv[r] = ld_stream(&ar.ln_prev[(size_t)base_i + r * PG_BLK + tid]);
         });
@@ -865,16 +872,16 @@ __global__ __launch_bounds__(PG_BLK, PG_STEP_OCC) void k_step(DevModel md, StepA
                 int spins = 0;
                 for (; spins < (1 << 16); ++spins) {
                     g = __hip_atomic_load(&sb_prev.hdr->ref_granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((unsigned)(g >> 32) == ar.tag) break;
+                    if ((unsigned)(g >> 32) == tag) break;
                     __builtin_amdgcn_s_sleep(8);
                 }
-                sm.cnt[1] = ((unsigned)(g >> 32) == ar.tag) ? (int)(unsigned)g : -1;
+                sm.cnt[1] = ((unsigned)(g >> 32) == tag) ? (int)(unsigned)g : -1;
             }
             __syncthreads();
             int ref_idx = sm.cnt[1];
             if (ref_idx < 0) {  // uniform: the word never arrived -- draw the ancestor here
                 __syncthreads();
-                ref_idx = cdf_count_wg_cold<LOCAL>(sm, sb_prev, pr, md.nseg_g, md.Ng, ar.u2_prev, ar.anc_in);
+                ref_idx = cdf_count_wg_cold<LOCAL>(sm, sb_prev, pr, md.nseg_g, md.Ng, u2_prev, ar.anc_in);
             }
 #pragma unroll
             for (int j = 0; j < PG_PPT; ++j)

@@ -423,6 +423,7 @@ def main():
     mark("warm-up done")
     t0 = time.perf_counter()
     prof_n, prof_ms, prop_n, prop_ms = 0, 0.0, 0, 0.0
+    graph_sweeps = 0
     for k in range(args.steps):
         # kernel durations: the LAST timed sweep launches every k_step / k_propagate with start/stop HIP events
         # (hipExtLaunchKernelGGL: the dispatch's own begin/end timestamps, on the streams the kernels run on).  Timing every
@@ -430,6 +431,7 @@ def main():
         timed_sweep = not args.no_profile and (k == args.steps - 1 or prof_all)
         eng.set_profiling((-1 if stride == 1 else stride) if timed_sweep else 0)
         traj_last = one_sweep(seed + k)
+        graph_sweeps += 1 if (grp is None and eng.launch_info()["graph"]) else 0
         if timed_sweep:
             n, ms, pn, pm = eng.profile()   # synchronises this sweep
             prof_n += n
@@ -469,6 +471,9 @@ def main():
             "particles_per_gpu": N, "particles_total": N * world if sharded_mode else N, "T": T,
             "partition": "particle-sharded" if sharded_mode else ("single GPU" if world == 1 else "replicas"),
             "hip_runtime_version": int(eng.lib.pgas_hip_runtime_version()),
+            "launch": ("every sweep enqueued launch by launch" if (sharded_mode or graph_sweeps == 0) else
+                       f"{graph_sweeps} of the {args.steps} timed sweeps replay the sweep's HIP graph (PGAS_GRAPH=1; captured once, in the warm-up); the sweep that carries "
+                       "the per-launch timing events is enqueued launch by launch"),
             "verified": verified,
             **({"self_check": self_check} if self_check else {}),
             "parallelism": "1 GPU" if world == 1 and not sharded_mode else (

@@ -89,6 +89,13 @@ int32_t pgas_segment_size(void);
 int pgas_set_params(pgas_ctx* ctx, const double* A_dev, const double* LS_host, const double* LSinv_host,
                     double cS, void* stream);
 
+/* The same with error_cov on the DEVICE: S_dev (nx,nx) row-major, symmetric positive definite.  Its Cholesky factor, the factor's
+ * inverse and the constant are formed by the pack kernel (IEEE sqrt, /, *, - and the shared logarithm, in a fixed order), so a Gibbs
+ * iteration -- PGAS.sample_params -> sweep, src/PGAS.py:366-378 -- needs no host round trip.  pgas_get_params reads back the factor,
+ * its inverse and the constant the kernels use (synchronises the stream; for tests and for replaying a chain with the oracle). */
+int pgas_set_params_dev(pgas_ctx* ctx, const double* A_dev, const double* S_dev, void* stream);
+int pgas_get_params(pgas_ctx* ctx, double* LS_host, double* LSinv_host, double* cS, void* stream);
+
 /* Test hook: phi (np,M) = basis_fcn(x[p], inputs[t]) in reference order
  * (vmap(basis_fcn) of src/PGAS.py:52-54). x_dev (np,nx). */
 int pgas_basis_eval(pgas_ctx* ctx, const double* x_dev, int64_t np, int32_t t, double* phi_dev, void* stream);
@@ -141,7 +148,8 @@ int pgas_set_profiling(pgas_ctx* ctx, int32_t on);
 int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample_ms, int64_t* propagate_launches,
                      double* propagate_ms, void* stream);
 /* What the last sweep launched: info4 = {time steps per k_propagate launch, group-scan placement (0: k_groups launches between the
- * steps, 1: k_step<LOCAL> scans all groups in every workgroup, 2: in k_step's tail by the workgroup that completes a group),
+ * steps, 1: k_step<LOCAL> scans all groups in every workgroup, 2: in k_step's tail by the workgroup that completes a group; + 16 when
+ * the last sweep replayed the captured HIP graph),
  * padded innermost basis extent JP, particles per basis pass P} -- bench.py labels its kernels from this. */
 int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 
@@ -161,6 +169,7 @@ int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 #define PGAS_OPT_SYRK_SPLITS 10 /* pgas_suffstats: number of row splits of the Z^T Z product (partial slabs summed in split order); 0 = automatic (about two workgroups per CU) */
 #define PGAS_OPT_TAIL_GROUPS 9 /* 1: single device only: the group scans ride in k_step's tail (in-launch hand-off to the workgroup that completes a group) instead of k_groups launches; measured slower, default 0 */
 #define PGAS_OPT_EVENT_STRIDE 8 /* k_propagate launches per event that gates the weight recursion's stream (default 8) */
+#define PGAS_OPT_GRAPH 13 /* 1: pgas_sweep captures its launches (k_init ... k_backtrace, both streams) once in a HIP graph and replays it per sweep on an internal stream -- seed, uniforms, transition parameters, reference trajectory and result all live in device memory the graph's kernels read at execution time; same kernels, same order: identical results.  0: enqueue every launch (what profiled sweeps, the corrected mode and sharded sweeps always do).  Default: off -- on the HIP 7.0 runtime bundled with PyTorch 2.10 the replay measured slower than enqueueing at every size */
 #define PGAS_OPT_TRACE_BLOCK_BYTES 12 /* before the first sweep / pgas_shard_setup: keep the traces in row blocks of at most this many bytes (0 = default: one array per trace on an unsharded context, 1 GiB blocks on a shard); small values are a test knob that puts block boundaries inside short sweeps */
 #define PGAS_OPT_MNIW_VALU 6 /* 1: pgas_m_mniw_solve factorises column by column on the VALU instead of in MFMA-blocked panels (test knob) */
 int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);

@@ -230,6 +230,30 @@ class CanonModel:
         cS = -0.5 * S.shape[0] * np.log(2 * np.pi) - np.sum(np.log(np.diag(LS)))
         return _f64(LS), _f64(LSinv), float(cS)
 
+    @staticmethod
+    def chol_parts_dev(S):
+        """The factorisation pgas_set_params_dev performs on the device (csrc/pgas_kernels.hip.h, k_pack), operation for operation in
+        IEEE double arithmetic: what a chain that keeps error_cov on the device runs its sweeps with (nx <= 2)."""
+        S = np.atleast_2d(np.asarray(S, dtype=np.float64))
+        nx = S.shape[0]
+        LS, LSinv = np.zeros((nx, nx)), np.zeros((nx, nx))
+        log2pi = np.float64(float.fromhex("0x1.d67f1c864beb4p+0"))
+        if nx == 1:
+            l = np.sqrt(S[0, 0])
+            LS[0, 0], LSinv[0, 0] = l, np.float64(1.0) / l
+            cS = np.float64(-0.5) * log2pi - det_log(np.array([l]))[0]
+        elif nx == 2:
+            l00 = np.sqrt(S[0, 0])
+            l10 = S[1, 0] / l00
+            l11 = np.sqrt(S[1, 1] - l10 * l10)
+            i00, i11 = np.float64(1.0) / l00, np.float64(1.0) / l11
+            LS[0, 0], LS[1, 0], LS[1, 1] = l00, l10, l11
+            LSinv[0, 0], LSinv[1, 0], LSinv[1, 1] = i00, -(l10 * i00) * i11, i11
+            cS = -log2pi - (det_log(np.array([l00]))[0] + det_log(np.array([l11]))[0])
+        else:
+            raise ValueError("chol_parts_dev: nx <= 2")
+        return _f64(LS), _f64(LSinv), float(cS)
+
     def step(self, t, seed, x_prev, logw_prev, A, LS, LSinv, cS, ref_t, debug=False):
         N, nx = self.N, self.nx
         x_prev = _f64(x_prev).reshape(N, nx)

@@ -139,7 +139,8 @@ def test_pgas_chain_against_restated_chain(name, N, K):
     L0 = np.linalg.cholesky(pb.init_state_cov)
 
     def sweep(seed, ref, A, S):
-        LS, LSinv, cS = cm.chol_parts(S)
+        # the chain keeps error_cov on the device and factors it there (pgas_set_params_dev); chol_parts_dev is that factorisation
+        LS, LSinv, cS = cm.chol_parts_dev(S)
         return cm.sweep(seed, ref, A, LS, LSinv, cS, pb.init_state_mean, L0)[0]
 
     nc = numpy_csmc(pb, N)   # literal NumPy callables (basis, likelihood) built from the reference formulas
@@ -151,3 +152,42 @@ def test_pgas_chain_against_restated_chain(name, N, K):
         np.testing.assert_allclose(A, Ao, rtol=1e-9, atol=1e-9 * np.abs(Ao).max(), err_msg=f"coeff_mat of iteration {k}")
         np.testing.assert_allclose(S, So, rtol=1e-9, atol=1e-12, err_msg=f"error_cov of iteration {k}")
     assert not np.array_equal(st[:, 0], st[:, K - 1]), "the chain must move"
+    # what the kernels ran the last sweep with is exactly that factorisation (and NumPy's to rounding)
+    LSd, LSinvd, cSd = pg.cSMC.engine.get_params()
+    A_last, S_last = pg.chain_log["params"][K - 1]
+    pg.cSMC.engine.set_params(A_last, S_last)
+    LSd, LSinvd, cSd = pg.cSMC.engine.get_params()
+    LSo, LSinvo, cSo = cm.chol_parts_dev(S_last.cpu().numpy())
+    assert np.array_equal(LSd, LSo) and np.array_equal(LSinvd, LSinvo) and cSd == cSo
+    LSn, LSinvn, cSn = cm.chol_parts(S_last.cpu().numpy())
+    np.testing.assert_allclose(LSd, LSn, rtol=1e-14, atol=0)
+    np.testing.assert_allclose(LSinvd, LSinvn, rtol=1e-13, atol=0)
+    assert abs(cSd - cSn) <= 1e-14 * abs(cSn)
+
+
+def test_gibbs_iterations_make_no_host_round_trip():
+    """A Gibbs iteration (sample_params -> set_params -> sweep, src/PGAS.py:360-378) enqueues work only: with device synchronisation made an
+    error (torch.cuda.set_sync_debug_mode) the chain still runs, i.e. no .cpu() / .item() / blocking copy hides in the loop."""
+    import torch
+
+    from common import experiments, pgas_amd
+
+    pb = experiments.toy(T=30)
+    pg = pgas_amd.PGAS(500, 3, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.GP_prior, pb.basis_fcn)
+    pg(7, pb.X_true)   # first call: allocations (those may synchronise)
+    torch.cuda.synchronize()
+    dev = pg.cSMC.device
+    ref = torch.as_tensor(pb.X_true, device=dev).reshape(pb.T, -1)
+    A, S = pg.sample_params(11, ref)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for k in range(3):
+            traj = pg.cSMC(100 + k, ref, A, S)
+            A, S = pg.sample_params(200 + k, traj.reshape(pb.T, -1))
+            ref = traj.reshape(pb.T, -1)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(A).all()) and bool(torch.isfinite(S).all())
+

@@ -87,6 +87,7 @@ def test_basis_init_step_bit_exact(name, N):
     ("toy", 1500, {1: 1}),            # PGAS_OPT_PROPAGATE_CHUNK = 1: one k_propagate launch per step
     ("smo", 5000, {8: 3, 11: 2}),     # PGAS_OPT_EVENT_STRIDE = 3, PGAS_OPT_MAX_LEAD = 2: k_propagate at most two event groups ahead of the chain
     ("smo", 5000, {3: 0}),            # PGAS_OPT_OVERLAP = 0: both pipelines on the caller's stream
+    ("smo", 5000, {13: 1}), ("emps", 2048, {13: 1}), ("toy", 300, {13: 1}), ("smo", 70000, {13: 1, 1: 7}),   # PGAS_OPT_GRAPH = 1: the sweep captured in a HIP graph and replayed
     ("smo", 5000, {12: 1 << 18}),     # PGAS_OPT_TRACE_BLOCK_BYTES: traces in row blocks (2 state rows, 4 hand-off rows, 8 ancestor rows per block)
     ("smo", 70000, {12: 4 << 20, 1: 7}),   # ... with k_propagate chunks of 7 steps that straddle block boundaries (split launches)
     ("emps", 2048, {12: 1 << 17}),    # ... 3-D basis, 4 state rows per block
@@ -131,6 +132,36 @@ def test_generic_propagate_variant_bit_exact(name, N, monkeypatch):
     _eq(traj, trajo.reshape(traj.shape), "trajectory")
     info = csmc.engine.launch_info()
     assert info["JP"] in (8, 12), info   # padded grid extent of the generic instantiations (the fast ones use the exact 7 / 9)
+
+
+def test_graph_replay_follows_seed_parameters_and_reference():
+    """The captured sweep (PGAS_OPT_GRAPH) is replayed with everything that changes between sweeps -- seed, uniforms,
+    (A, S), reference trajectory -- read from device memory at execution time: three replays with different inputs, then the first
+    inputs again, each bit-identical to the oracle (and the first and last to each other)."""
+    pb = experiments.smo_pgas(T=20)
+    N = 6000
+    A, S = experiments.initial_params(pb)
+    cm = canon_model(pb, N)
+    csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn, pb.basis_fcn)
+    csmc.engine.set_option(13, 1)   # PGAS_OPT_GRAPH (off by default: slower than enqueueing on this runtime, DESIGN.md section 8)
+    L0 = np.linalg.cholesky(pb.init_state_cov)
+    rng = np.random.default_rng(4)
+    cases = [(SEED, A, S, pb.X_true),
+             (SEED + 1, A * 0.97, S * 1.3, pb.X_true + 1e-3 * rng.standard_normal(pb.X_true.shape)),
+             (SEED + 2, A + 1e-3 * rng.standard_normal(A.shape), S, pb.X_true),
+             (SEED, A, S, pb.X_true)]
+    got = []
+    for seed, a, s_, ref in cases:
+        LS, LSinv, cS = cm.chol_parts(s_)
+        traj = csmc(seed, ref, a, s_)
+        trajo, Xo, ANCo, lwo = cm.sweep(seed, ref, a, LS, LSinv, cS, pb.init_state_mean, L0)
+        X, ANC, LW, _ = csmc.engine.traces()
+        _eq(X, Xo, "state_trace")
+        _eq(ANC[: pb.T - 1], ANCo, "ancestor_trace")
+        _eq(traj, trajo.reshape(traj.shape), "trajectory")
+        assert csmc.engine.launch_info()["graph"]
+        got.append(traj.cpu().numpy())
+    assert np.array_equal(got[0], got[3]) and not np.array_equal(got[0], got[1])
 
 
 def test_sweep_degenerate_weights():
