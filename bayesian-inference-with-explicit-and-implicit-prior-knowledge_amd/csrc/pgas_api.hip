@@ -96,6 +96,8 @@ typedef void (*aux_fn)(DevModel, const TransParams*, int, const double*, double*
 typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, Peers, int32_t*, double*);
 typedef void (*init_fn)(DevModel, uint64_t, const SweepParams*, const double*, const double*, double*);
 typedef void (*basis_fn)(DevModel, const int32_t*, const double*, int64_t, int, double*);
+typedef void (*small_fn)(DevModel, const TransParams*, const double*, const SweepParams*, const double*, const double*, const double*, const double*, double*, int32_t*,
+                         double*, double*, UpperHdr*, double*);
 
 struct Variant {
     front_fn front;
@@ -104,12 +106,13 @@ struct Variant {
     aux_fn aux;
     int P, W;   // particles per basis pass, waves per SIMD the k_propagate instantiation is built for
     int PPT;    // particles per thread of k_propagate: its grid is ceil(nseg / (PPT / 4))
+    small_fn small;   // the whole sweep in one workgroup (N <= 1024)
 };
 
 template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT>
 Variant make_variant() {
     const prop_fn one = k_propagate<NX, D, JIN, P, W, J0T, PPT, true>;
-    return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W, J0T, PPT>, one, k_aux<NX, D, JIN, P>, P, W, PPT};
+    return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W, J0T, PPT>, one, k_aux<NX, D, JIN, P>, P, W, PPT, k_sweep_small<NX, D, JIN, J0T>};
 }
 
 // (nx, D, padded innermost extent) -> kernel instantiation <NX, D, JIN, P particles per basis pass, W waves/SIMD>
@@ -205,6 +208,8 @@ struct pgas_ctx {
     hipGraphExec_t graph_exec = nullptr;
     int graph_key[6] = {-1, -1, -1, -1, -1, -1};   // launch configuration the graph was captured with
     int last_graph = 0;            // 1: the last pgas_sweep replayed the captured graph
+    int use_small = 1;             // PGAS_OPT_SMALL_SWEEP: contexts of at most one segment run the whole sweep in one workgroup (k_sweep_small)
+    int last_small = 0;            // 1: the last pgas_sweep did
     int graph_failed = 0;          // capture or instantiation failed once: stay on the eager path
     hipStream_t sG = nullptr;      // the stream captured sweeps are recorded on and replayed on (the caller's may be the legacy default
                                    // stream, which cannot be captured); ordered against the caller's stream with ev_g0 / ev_g1
@@ -1046,13 +1051,31 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
             HIPCHK(c, hipMemcpyAsync(c->logw_last, c->logw_trace + (size_t)(T - 1) * N, N * sizeof(double), hipMemcpyDeviceToDevice, st));
         return run_final(c, traj_dev, st);
     }
+    c->last_small = 0;
+    c->last_graph = 0;
+    if (c->use_small && N <= PGAS_SEG && !c->profiling && c->rs[PG_RB_X].contiguous && c->rs[PG_RB_ANC].contiguous) {
+        // at most one segment of particles: the whole sweep -- x_0, T-1 steps, final index, back-trace -- is ONE launch of ONE workgroup
+        rc = sweep_begin(c, seed, st);
+        if (rc) return rc;
+        size_t lds = 0;
+        if (md.D == 3) {
+            lds = (size_t)c->gtotal * sizeof(double);
+            if (lds > 64 * 1024) FAIL(c, PGAS_E_ARG, "k_sweep_small: coefficient tensor of %zu bytes does not fit the LDS budget", lds);
+        }
+        hipLaunchKernelGGL(c->var.small, dim3(1), dim3(PG_BLK), lds, st, md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp,
+                           (const double*)c->d_ures, (const double*)c->d_uanc, (const double*)c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].blk[0],
+                           (int32_t*)c->rs[PG_RB_ANC].blk[0], c->logw_last, c->logw_trace, c->sb[T & 1].hdr, traj_dev);
+        KCHK(c, "k_sweep_small");
+        c->last_small = 1;
+        c->last_chunk = 1;
+        return PGAS_OK;
+    }
     // default chunk, measured (tools/ab_bench.py --chunk, tools/config_times.py): one step per k_propagate launch
     const int chunk = c->prop_chunk > 0 ? c->prop_chunk : (c->overlap ? 1 : T);
     c->last_chunk = chunk;
     // PGAS_OPT_GRAPH (default on): the ~6000 launches of a sweep are captured once and replayed; launches that carry timing events
     // (pgas_set_profiling) and the development knobs that wait across streams stay on the eager path
     const int key[6] = {chunk, c->overlap, c->ev_stride, sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0), c->prop_lds, c->keep_logw};
-    c->last_graph = 0;
     const bool want_graph = c->use_graph == 1 || (c->use_graph < 0 && md.N <= PG_GRAPH_AUTO_N);
     if (want_graph && !c->profiling && c->max_lead == 0 && sweep_graph_ready(c, key, chunk)) {
         // the replay runs on the library's own stream, behind everything the caller has enqueued and in front of what it enqueues next
@@ -1172,6 +1195,10 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         c->prop_lds = (int)value;
         return PGAS_OK;
     }
+    if (option == PGAS_OPT_SMALL_SWEEP) {
+        c->use_small = value ? 1 : 0;
+        return PGAS_OK;
+    }
     if (option == PGAS_OPT_GRAPH) {
         c->use_graph = value ? 1 : 0;
         return PGAS_OK;
@@ -1226,7 +1253,7 @@ int pgas_get_launch_info(pgas_ctx* c, int32_t* info4) {
     if (!c) return PGAS_E_ARG;
     if (!info4) FAIL(c, PGAS_E_ARG, "pgas_get_launch_info: NULL argument");
     info4[0] = c->last_chunk;
-    info4[1] = (sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0)) + (c->last_graph ? 16 : 0);   // + 16: the last sweep replayed the captured graph
+    info4[1] = (c->last_small ? 3 : (sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0))) + (c->last_graph ? 16 : 0);   // + 16: the last sweep replayed the captured graph
     info4[2] = c->md.JP;
     info4[3] = c->var_P;
     return PGAS_OK;

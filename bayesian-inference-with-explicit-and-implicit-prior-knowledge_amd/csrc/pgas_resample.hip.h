@@ -1018,3 +1018,258 @@ __global__ void k_detmath(int which, const double* __restrict__ x, const double*
     default: break;
     }
 }
+
+// ------------------------------------------------------------------------------------------
+// k_sweep_small: the WHOLE sweep (src/PGAS.py:176-228) of a context with at most one segment of particles (N <= 1024: the
+// reference's own operating point, N = 200 in src/Toy_Example.py:137 / src/EMPS.py:245) in ONE launch of ONE workgroup.
+// The multi-kernel path needs ~3 dependent launches per time step whatever N is (15 us per step at N = 200: launch latency);
+// here a step is a handful of workgroup barriers: states and log-weights stay in registers, the two fixed-point CDFs, the
+// log-likelihoods of the auxiliary states and the exchange arrays live in LDS, only the traces go to memory.
+//
+// Same arithmetic as the general path, bit for bit.  With a single segment the hierarchical CDF of DESIGN.md 4.4 collapses:
+// group and top references equal the segment's (all scales are exactly 1, all prefixes exactly 0), so
+//   num_k = c_k 2^-51,   S = s 2^-51   (c_k the integer cumsum, s its total)
+// and the systematic-resampling search, the ancestor draw and the final index are counts #{k : num_k < tau} against that.
+// ------------------------------------------------------------------------------------------
+struct SmallSmem {
+    uint64_t q[2][PGAS_SEG];     // numerators in particle order (transposition for the prefix sums)
+    double num[2][PGAS_SEG];     // CDF numerators of the resampling / ancestor weights, +inf past N
+    double la[PGAS_SEG];         // log p(y_t | aux_t) by particle
+    double red[2][PG_BLK / 64];
+    uint64_t wtot[2][PG_BLK / 64];
+    int cnt[PG_BLK / 64];
+};
+
+// fixed-point CDFs of NW weight vectors of the one segment into sm.num[w] (thread -> particles r * 256 + tid); returns S per vector
+template <int NW>
+__device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW][PG_PPT], int n, double (&S)[NW]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        double m = -__builtin_inf();
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) m = __builtin_fmax(m, lw[w][r]);
+        m = wave_max(m);
+        if (lane == 0) sm.red[w][wave] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        double m = sm.red[w][0];
+#pragma unroll
+        for (int v = 1; v < PG_BLK / 64; ++v) m = __builtin_fmax(m, sm.red[w][v]);
+        const double kref = pgas_seg_ref(m);
+        double arg[PG_PPT];
+        uint64_t qv[PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) arg[r] = pgas_seg_arg(lw[w][r], kref);
+        dev_exp_q51_n<PG_PPT>(arg, qv);
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) sm.q[w][r * PG_BLK + tid] = qv[r];
+    }
+    __syncthreads();
+    uint64_t loc[NW][PG_PPT], incl[NW];
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        uint64_t run = 0;
+#pragma unroll
+        for (int j = 0; j < PG_PPT; ++j) {
+            run += sm.q[w][PG_PPT * tid + j];
+            loc[w][j] = run;
+        }
+        incl[w] = wave_incl_scan_u64(run);
+        if (lane == 63) sm.wtot[w][wave] = incl[w];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        uint64_t off = 0, tot = 0;
+#pragma unroll
+        for (int v = 0; v < PG_BLK / 64; ++v) {
+            const uint64_t t = sm.wtot[w][v];
+            if (v < wave) off += t;
+            tot += t;
+        }
+        const uint64_t base = off + incl[w] - loc[w][PG_PPT - 1];
+#pragma unroll
+        for (int j = 0; j < PG_PPT; ++j) {
+            const int k = PG_PPT * tid + j;
+            sm.num[w][k] = k < n ? pgas_u64_to_double(base + loc[w][j]) * PGAS_FIX_INV : __builtin_inf();
+        }
+        S[w] = pgas_u64_to_double(tot) * PGAS_FIX_INV;
+    }
+    __syncthreads();
+}
+
+// #{k : num[k] < tau} over the +inf padded segment (branch-free lower bound)
+__device__ __forceinline__ int small_lower_bound(const double* __restrict__ num, double tau) {
+    int p = 0;
+#pragma unroll
+    for (int step = PGAS_SEG / 2; step >= 1; step >>= 1)
+        if (num[p + step - 1] < tau) p += step;
+    return p;
+}
+
+// the same count for ONE threshold by the whole workgroup (ancestor of the conditioned particle, final index)
+__device__ __forceinline__ int small_count(SmallSmem& sm, const double* __restrict__ num, double tau) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int k = 0;
+#pragma unroll
+    for (int j = 0; j < PG_PPT; ++j) k += (num[j * PG_BLK + tid] < tau) ? 1 : 0;
+    k = wave_sum_i(k);
+    if (lane == 0) sm.cnt[wave] = k;
+    __syncthreads();
+    int tot = 0;
+#pragma unroll
+    for (int v = 0; v < PG_BLK / 64; ++v) tot += sm.cnt[v];
+    __syncthreads();
+    return tot;
+}
+
+template <int NX, int D, int JIN, int J0T>
+__global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const TransParams* __restrict__ tpp, const double* __restrict__ G_arg,
+                                                        const SweepParams* __restrict__ swp, const double* __restrict__ u_res,
+                                                        const double* __restrict__ u_anc, const double* __restrict__ m0L0,
+                                                        const double* __restrict__ ref, double* __restrict__ x_trace,
+                                                        int32_t* __restrict__ anc_trace, double* __restrict__ logw_last,
+                                                        double* __restrict__ logw_trace /* (T, N) or NULL */, UpperHdr* __restrict__ hdr,
+                                                        double* __restrict__ traj) {
+    __shared__ SmallSmem sm;
+    const int tid = threadIdx.x;
+    const int N = md.N, T = md.T;
+    const int nr = (N + PG_BLK - 1) / PG_BLK;   // particle rows in use (uniform): particle i = r * 256 + tid, r < nr
+    const size_t row = (size_t)N * NX;
+    TransParams tp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        tp.LS[q] = ld_const(&tpp->LS[q]);
+        tp.LSinv[q] = ld_const(&tpp->LSinv[q]);
+    }
+    tp.cS = ld_const(&tpp->cS);
+    tp.G = G_arg;
+    const uint64_t seed = ld_const(&swp->seed);
+    const double* Guse = G_arg;
+    if constexpr (D == 3) {   // coefficient tensor in LDS, as in k_propagate
+        extern __shared__ __attribute__((aligned(16))) double pg_g_lds_small[];
+        const int gtot = md.J[0] * md.J[1] * JIN * NX;
+        for (int i = tid; i < gtot; i += PG_BLK) pg_g_lds_small[i] = G_arg[i];
+        __syncthreads();
+        Guse = pg_g_lds_small;
+    }
+    const bool pow2 = (N & (N - 1)) == 0;
+    const double invN = 1.0 / (double)N;
+
+    // ---- x_0 ~ N(m0, P0), conditioned particle = ref_0 (src/PGAS.py:155-174,194)
+    double x[PG_PPT][NX], logw[PG_PPT];
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) {
+        const int i = r * PG_BLK + tid;
+        logw[r] = 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) x[r][k] = 0.0;
+        if (r < nr) {   // uniform
+            double z[2];
+            pgas_rng_normals(seed, PGAS_STREAM_INIT, 0u, (uint64_t)(i < N ? i : N - 1), NX, z);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                double v = m0L0[k];
+#pragma unroll
+                for (int l = 0; l <= k; ++l) v = PGAS_FMA(m0L0[NX + k * NX + l], z[l], v);
+                x[r][k] = (i == N - 1) ? ref[k] : v;
+            }
+            if (i < N) {
+#pragma unroll
+                for (int k = 0; k < NX; ++k) x_trace[(size_t)i * NX + k] = x[r][k];
+            }
+        }
+    }
+    if (logw_trace != nullptr) {
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r)
+            if (r * PG_BLK + tid < N) logw_trace[r * PG_BLK + tid] = 0.0;
+    }
+
+    // ---- the time loop (src/PGAS.py:199-221)
+    for (int t = 1; t < T; ++t) {
+        const double* __restrict__ yt = md.y + (size_t)t * md.ny;
+        const double* __restrict__ ut = md.u + (size_t)t * md.nu;
+        double rf[NX];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) rf[k] = ref[(size_t)t * NX + k];
+        double lw[2][PG_PPT], ln[PG_PPT];
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            lw[0][r] = -__builtin_inf();
+            lw[1][r] = -__builtin_inf();
+            ln[r] = 0.0;
+            if (r < nr) {   // uniform
+                const int i = r * PG_BLK + tid;
+                double xin[1][NX], xn[1][NX], la1[1], h1[1], ln1[1];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) xin[0][k] = x[r][k];
+                propagate_group<NX, D, JIN, 1, J0T>(md, tp, Guse, t, seed, rf, yt, ut, 0, r, xin, xn, la1, h1, ln1);
+                if (i < N) {
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) {
+                        x[r][k] = xn[0][k];
+                        st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xn[0][k]);
+                    }
+                    const double l1 = la1[0] + logw[r];   // src/PGAS.py:101-102
+                    lw[0][r] = l1;
+                    lw[1][r] = l1 + h1[0];                // :117-118
+                    ln[r] = ln1[0];
+                }
+                sm.la[i] = la1[0];
+            }
+        }
+        double S[2];
+        small_scan<2>(sm, lw, N, S);   // ends with a barrier: sm.num and sm.la are visible
+        // ---- systematic resampling (src/Filtering.py:28-35) and the ancestor of the conditioned particle (src/PGAS.py:121-127)
+        const double u1 = u_res[t], u2 = u_anc[t];
+        const bool valid1 = (S[0] > 0.0) && (S[0] < __builtin_inf()), valid2 = (S[1] > 0.0) && (S[1] < __builtin_inf());
+        const int cnt2 = small_count(sm, sm.num[1], u2 * S[1]);
+        const int ref_idx = valid2 ? (cnt2 > N - 1 ? N - 1 : cnt2) : N - 1;
+#pragma unroll
+        for (int r = 0; r < PG_PPT; ++r) {
+            const int i = r * PG_BLK + tid;
+            if (r < nr && i < N) {
+                int a = i;   // no positive weight: identity (src/Filtering.py:25)
+                if (valid1) {
+                    const int p = small_lower_bound(sm.num[0], slot_U(u1, i, N, invN, pow2) * S[0]);
+                    a = p > N - 1 ? N - 1 : p;
+                }
+                if (i == N - 1) a = ref_idx;
+                st_stream(&anc_trace[(size_t)(t - 1) * N + i], (int32_t)a);
+                logw[r] = ln[r] - sm.la[a];   // src/PGAS.py:137-147
+                if (logw_trace != nullptr) logw_trace[(size_t)t * N + i] = logw[r];
+            }
+        }
+        __syncthreads();   // sm.la / sm.num are rewritten by the next step
+    }
+
+    // ---- final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
+    double lwf[1][PG_PPT];
+#pragma unroll
+    for (int r = 0; r < PG_PPT; ++r) {
+        const int i = r * PG_BLK + tid;
+        lwf[0][r] = (r < nr && i < N) ? logw[r] : -__builtin_inf();
+        if (r < nr && i < N) logw_last[i] = logw[r];
+    }
+    double Sf[1];
+    small_scan<1>(sm, lwf, N, Sf);
+    const bool validf = (Sf[0] > 0.0) && (Sf[0] < __builtin_inf());
+    const int cf = small_count(sm, sm.num[0], ld_const(&swp->u_final) * Sf[0]);
+    const int fidx = validf ? (cf > N - 1 ? N - 1 : cf) : N - 1;
+    // the traces were written by every wave of this workgroup: make them visible to the one lane that chases
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        hdr->final_idx = fidx;
+        int b = fidx;
+        for (int i = T - 1; i >= 0; --i) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) traj[(size_t)i * NX + k] = __hip_atomic_load(&x_trace[(size_t)i * row + (size_t)b * NX + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i > 0) b = __hip_atomic_load(&anc_trace[(size_t)(i - 1) * N + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}

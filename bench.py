@@ -503,7 +503,7 @@ def main():
             p_us = 1e3 * prop_ms / max(prop_n, 1)
             p_steps = max(info["chunk"], 1)
             p_us_step = p_us / p_steps
-            kname_step = {"local": "k_step<LOCAL>", "tail": "k_step<TAIL>", "k_groups": "k_step (+ k_groups launch)"}[info["groups"]]
+            kname_step = {"local": "k_step<LOCAL>", "tail": "k_step<TAIL>", "k_groups": "k_step (+ k_groups launch)", "small": "k_sweep_small"}[info["groups"]]
             nxv, Dv = pb.nx, len(pb.basis_fcn.sel)
             kname_prop = f"k_propagate<{nxv},{Dv},{info['JP']},{info['P']}>"
             per_launch = ALG_BYTES_PER_PARTICLE_STEP * N

@@ -148,7 +148,8 @@ int pgas_set_profiling(pgas_ctx* ctx, int32_t on);
 int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample_ms, int64_t* propagate_launches,
                      double* propagate_ms, void* stream);
 /* What the last sweep launched: info4 = {time steps per k_propagate launch, group-scan placement (0: k_groups launches between the
- * steps, 1: k_step<LOCAL> scans all groups in every workgroup, 2: in k_step's tail by the workgroup that completes a group; + 16 when
+ * steps, 1: k_step<LOCAL> scans all groups in every workgroup, 2: in k_step's tail by the workgroup that completes a group, 3: no group
+ * scans at all -- the single-workgroup sweep k_sweep_small ran; + 16 when
  * the last sweep replayed the captured HIP graph),
  * padded innermost basis extent JP, particles per basis pass P} -- bench.py labels its kernels from this. */
 int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
@@ -169,6 +170,7 @@ int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 #define PGAS_OPT_SYRK_SPLITS 10 /* pgas_suffstats: number of row splits of the Z^T Z product (partial slabs summed in split order); 0 = automatic (about two workgroups per CU) */
 #define PGAS_OPT_TAIL_GROUPS 9 /* 1: single device only: the group scans ride in k_step's tail (in-launch hand-off to the workgroup that completes a group) instead of k_groups launches; measured slower, default 0 */
 #define PGAS_OPT_EVENT_STRIDE 8 /* k_propagate launches per event that gates the weight recursion's stream (default 8) */
+#define PGAS_OPT_SMALL_SWEEP 14 /* 1 (default): a context of at most one segment of particles (N <= 1024 -- the reference's own operating point, N = 200) runs the whole sweep, x_0 to back-trace, as ONE launch of ONE workgroup (k_sweep_small: weights, both fixed-point CDFs and the exchange arrays in LDS, states in registers) instead of ~3 dependent launches per time step; 0: the general multi-launch path at every size.  Bit-identical results */
 #define PGAS_OPT_GRAPH 13 /* 1: pgas_sweep captures its launches (k_init ... k_backtrace, both streams) once in a HIP graph and replays it per sweep on an internal stream -- seed, uniforms, transition parameters, reference trajectory and result all live in device memory the graph's kernels read at execution time; same kernels, same order: identical results.  0: enqueue every launch (what profiled sweeps, the corrected mode and sharded sweeps always do).  Default: off -- on the HIP 7.0 runtime bundled with PyTorch 2.10 the replay measured slower than enqueueing at every size */
 #define PGAS_OPT_TRACE_BLOCK_BYTES 12 /* before the first sweep / pgas_shard_setup: keep the traces in row blocks of at most this many bytes (0 = default: one array per trace on an unsharded context, 1 GiB blocks on a shard); small values are a test knob that puts block boundaries inside short sweeps */
 #define PGAS_OPT_MNIW_VALU 6 /* 1: pgas_m_mniw_solve factorises column by column on the VALU instead of in MFMA-blocked panels (test knob) */

@@ -92,7 +92,10 @@ def test_basis_init_step_bit_exact(name, N):
     ("smo", 70000, {12: 4 << 20, 1: 7}),   # ... with k_propagate chunks of 7 steps that straddle block boundaries (split launches)
     ("emps", 2048, {12: 1 << 17}),    # ... 3-D basis, 4 state rows per block
     ("toy", 1500, {12: 16384}),       # ... one row per block
-    # N <= 1024: one segment, one group
+    # N <= 1024: one segment -- by default the whole sweep is one launch of one workgroup (k_sweep_small); 14: 0 = PGAS_OPT_SMALL_SWEEP off,
+    # the general multi-launch path at the same sizes
+    ("smo", 200, {14: 0}), ("smo", 1024, {14: 0}), ("toy", 300, {14: 0}), ("emps", 500, {14: 0}), ("veh", 640, {14: 0}), ("smo", 777, {14: 0, 7: 1}), ("toy", 1, {14: 0}),
+    ("smo", 256, {}), ("smo", 257, {}), ("toy", 1024, {}), ("emps27", 1000, {}), ("smo", 513, {13: 1, 14: 0}),
     ("smo", 1024, {}), ("smo", 777, {}), ("toy", 300, {}), ("toy", 1, {}), ("emps", 500, {}), ("veh", 640, {}), ("veh27", 1000, {}), ("smo", 777, {7: 1}),
 ])
 def test_sweep_bit_exact(name, N, opts):
@@ -107,6 +110,7 @@ def test_sweep_bit_exact(name, N, opts):
     _eq(ANC[: pb.T - 1], ANCo, "ancestor_trace")
     _eq(LW, lwo, "log_weights_trace[-1]")
     _eq(traj, trajo.reshape(traj.shape), "trajectory")
+    assert csmc.engine.launch_info()["small"] == (N <= 1024 and opts.get(14, 1) == 1), "which sweep ran"
     # the trajectory is a path through the trace (src/Filtering.py:40-55)
     b = csmc.engine.last_final_index()
     Xn, An = X.cpu().numpy(), ANC.cpu().numpy()
@@ -183,9 +187,9 @@ def test_sweep_degenerate_weights():
     assert len(np.unique(ANCo[4])) < N // 4  # the step really was degenerate
 
 
-def test_logw_trace_option():
+@pytest.mark.parametrize("N", [3000, 300])
+def test_logw_trace_option(N):
     pb = experiments.smo_pgas(T=8)
-    N = 3000
     A, S = experiments.initial_params(pb)
     cm = canon_model(pb, N)
     csmc = pgas_amd.condSequentialMonteCarlo(N, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov,
