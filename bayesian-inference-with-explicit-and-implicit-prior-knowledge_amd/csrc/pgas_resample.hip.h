@@ -1040,15 +1040,16 @@ struct SmallSmem {
     int cnt[PG_BLK / 64];
 };
 
-// fixed-point CDFs of NW weight vectors of the one segment into sm.num[w] (thread -> particles r * 256 + tid); returns S per vector
-template <int NW>
-__device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW][PG_PPT], int n, double (&S)[NW]) {
+// fixed-point CDFs of NW weight vectors of the one segment into sm.num[w] (thread -> particles r * 256 + tid, r < NR); returns S per vector.
+// NR = particle rows in use (1, 2 or 4: N <= 256, 512, 1024): rows beyond it hold no particle and cost nothing.
+template <int NW, int NR>
+__device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW][NR], int n, double (&S)[NW]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         double m = -__builtin_inf();
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) m = __builtin_fmax(m, lw[w][r]);
+        for (int r = 0; r < NR; ++r) m = __builtin_fmax(m, lw[w][r]);
         m = wave_max(m);
         if (lane == 0) sm.red[w][wave] = m;
     }
@@ -1059,22 +1060,22 @@ __device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW]
 #pragma unroll
         for (int v = 1; v < PG_BLK / 64; ++v) m = __builtin_fmax(m, sm.red[w][v]);
         const double kref = pgas_seg_ref(m);
-        double arg[PG_PPT];
-        uint64_t qv[PG_PPT];
+        double arg[NR];
+        uint64_t qv[NR];
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) arg[r] = pgas_seg_arg(lw[w][r], kref);
-        dev_exp_q51_n<PG_PPT>(arg, qv);
+        for (int r = 0; r < NR; ++r) arg[r] = pgas_seg_arg(lw[w][r], kref);
+        dev_exp_q51_n<NR>(arg, qv);
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) sm.q[w][r * PG_BLK + tid] = qv[r];
+        for (int r = 0; r < NR; ++r) sm.q[w][r * PG_BLK + tid] = qv[r];
     }
     __syncthreads();
-    uint64_t loc[NW][PG_PPT], incl[NW];
+    uint64_t loc[NW][NR], incl[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         uint64_t run = 0;
 #pragma unroll
-        for (int j = 0; j < PG_PPT; ++j) {
-            run += sm.q[w][PG_PPT * tid + j];
+        for (int j = 0; j < NR; ++j) {
+            run += sm.q[w][NR * tid + j];
             loc[w][j] = run;
         }
         incl[w] = wave_incl_scan_u64(run);
@@ -1090,10 +1091,10 @@ __device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW]
             if (v < wave) off += t;
             tot += t;
         }
-        const uint64_t base = off + incl[w] - loc[w][PG_PPT - 1];
+        const uint64_t base = off + incl[w] - loc[w][NR - 1];
 #pragma unroll
-        for (int j = 0; j < PG_PPT; ++j) {
-            const int k = PG_PPT * tid + j;
+        for (int j = 0; j < NR; ++j) {
+            const int k = NR * tid + j;
             sm.num[w][k] = k < n ? pgas_u64_to_double(base + loc[w][j]) * PGAS_FIX_INV : __builtin_inf();
         }
         S[w] = pgas_u64_to_double(tot) * PGAS_FIX_INV;
@@ -1101,21 +1102,23 @@ __device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW]
     __syncthreads();
 }
 
-// #{k : num[k] < tau} over the +inf padded segment (branch-free lower bound)
+// #{k < span : num[k] < tau} over the +inf padded segment (branch-free lower bound; span = NR * 256, a power of two)
+template <int SPAN>
 __device__ __forceinline__ int small_lower_bound(const double* __restrict__ num, double tau) {
     int p = 0;
 #pragma unroll
-    for (int step = PGAS_SEG / 2; step >= 1; step >>= 1)
+    for (int step = SPAN / 2; step >= 1; step >>= 1)
         if (num[p + step - 1] < tau) p += step;
-    return p;
+    return (num[p] < tau) ? p + 1 : p;   // the element the halving never looks at: index SPAN - 1
 }
 
 // the same count for ONE threshold by the whole workgroup (ancestor of the conditioned particle, final index)
+template <int NR>
 __device__ __forceinline__ int small_count(SmallSmem& sm, const double* __restrict__ num, double tau) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int k = 0;
 #pragma unroll
-    for (int j = 0; j < PG_PPT; ++j) k += (num[j * PG_BLK + tid] < tau) ? 1 : 0;
+    for (int j = 0; j < NR; ++j) k += (num[j * PG_BLK + tid] < tau) ? 1 : 0;
     k = wave_sum_i(k);
     if (lane == 0) sm.cnt[wave] = k;
     __syncthreads();
@@ -1126,7 +1129,7 @@ __device__ __forceinline__ int small_count(SmallSmem& sm, const double* __restri
     return tot;
 }
 
-template <int NX, int D, int JIN, int J0T>
+template <int NX, int D, int JIN, int J0T, int NR>
 __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const TransParams* __restrict__ tpp, const double* __restrict__ G_arg,
                                                         const SweepParams* __restrict__ swp, const double* __restrict__ u_res,
                                                         const double* __restrict__ u_anc, const double* __restrict__ m0L0,
@@ -1135,9 +1138,10 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
                                                         double* __restrict__ logw_trace /* (T, N) or NULL */, UpperHdr* __restrict__ hdr,
                                                         double* __restrict__ traj) {
     __shared__ SmallSmem sm;
+    extern __shared__ __attribute__((aligned(16))) double pg_g_lds_small[];   // the coefficient tensor (every basis shape: one wave per SIMD
+                                                                               // has nothing to hide a scalar load per grid row behind)
     const int tid = threadIdx.x;
-    const int N = md.N, T = md.T;
-    const int nr = (N + PG_BLK - 1) / PG_BLK;   // particle rows in use (uniform): particle i = r * 256 + tid, r < nr
+    const int N = md.N, T = md.T;   // particle i = r * 256 + tid, r < NR
     const size_t row = (size_t)N * NX;
     TransParams tp;
 #pragma unroll
@@ -1148,45 +1152,37 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
     tp.cS = ld_const(&tpp->cS);
     tp.G = G_arg;
     const uint64_t seed = ld_const(&swp->seed);
-    const double* Guse = G_arg;
-    if constexpr (D == 3) {   // coefficient tensor in LDS, as in k_propagate
-        extern __shared__ __attribute__((aligned(16))) double pg_g_lds_small[];
-        const int gtot = md.J[0] * md.J[1] * JIN * NX;
+    {
+        int gtot = NX;
+#pragma unroll
+        for (int d = 0; d < D; ++d) gtot *= (d == D - 1 && D > 1) ? JIN : md.J[d];
         for (int i = tid; i < gtot; i += PG_BLK) pg_g_lds_small[i] = G_arg[i];
         __syncthreads();
-        Guse = pg_g_lds_small;
     }
+    const double* Guse = pg_g_lds_small;
     const bool pow2 = (N & (N - 1)) == 0;
     const double invN = 1.0 / (double)N;
 
     // ---- x_0 ~ N(m0, P0), conditioned particle = ref_0 (src/PGAS.py:155-174,194)
-    double x[PG_PPT][NX], logw[PG_PPT];
+    double x[NR][NX], logw[NR];
 #pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int i = r * PG_BLK + tid;
         logw[r] = 0.0;
+        double z[2];
+        pgas_rng_normals(seed, PGAS_STREAM_INIT, 0u, (uint64_t)(i < N ? i : N - 1), NX, z);
 #pragma unroll
-        for (int k = 0; k < NX; ++k) x[r][k] = 0.0;
-        if (r < nr) {   // uniform
-            double z[2];
-            pgas_rng_normals(seed, PGAS_STREAM_INIT, 0u, (uint64_t)(i < N ? i : N - 1), NX, z);
+        for (int k = 0; k < NX; ++k) {
+            double v = m0L0[k];
 #pragma unroll
-            for (int k = 0; k < NX; ++k) {
-                double v = m0L0[k];
-#pragma unroll
-                for (int l = 0; l <= k; ++l) v = PGAS_FMA(m0L0[NX + k * NX + l], z[l], v);
-                x[r][k] = (i == N - 1) ? ref[k] : v;
-            }
-            if (i < N) {
-#pragma unroll
-                for (int k = 0; k < NX; ++k) x_trace[(size_t)i * NX + k] = x[r][k];
-            }
+            for (int l = 0; l <= k; ++l) v = PGAS_FMA(m0L0[NX + k * NX + l], z[l], v);
+            x[r][k] = (i == N - 1) ? ref[k] : v;
         }
-    }
-    if (logw_trace != nullptr) {
+        if (i < N) {
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r)
-            if (r * PG_BLK + tid < N) logw_trace[r * PG_BLK + tid] = 0.0;
+            for (int k = 0; k < NX; ++k) x_trace[(size_t)i * NX + k] = x[r][k];
+            if (logw_trace != nullptr) logw_trace[i] = 0.0;
+        }
     }
 
     // ---- the time loop (src/PGAS.py:199-221)
@@ -1196,50 +1192,47 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
         double rf[NX];
 #pragma unroll
         for (int k = 0; k < NX; ++k) rf[k] = ref[(size_t)t * NX + k];
-        double lw[2][PG_PPT], ln[PG_PPT];
+        const double u1 = u_res[t], u2 = u_anc[t];
+        double lw[2][NR], ln[NR];
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
+        for (int r = 0; r < NR; ++r) {
+            const int i = r * PG_BLK + tid;
+            double xin[1][NX], xn[1][NX], la1[1], h1[1], ln1[1];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) xin[0][k] = x[r][k];
+            propagate_group<NX, D, JIN, 1, J0T>(md, tp, Guse, t, seed, rf, yt, ut, 0, r, xin, xn, la1, h1, ln1);
             lw[0][r] = -__builtin_inf();
             lw[1][r] = -__builtin_inf();
-            ln[r] = 0.0;
-            if (r < nr) {   // uniform
-                const int i = r * PG_BLK + tid;
-                double xin[1][NX], xn[1][NX], la1[1], h1[1], ln1[1];
+            ln[r] = ln1[0];
+            if (i < N) {
 #pragma unroll
-                for (int k = 0; k < NX; ++k) xin[0][k] = x[r][k];
-                propagate_group<NX, D, JIN, 1, J0T>(md, tp, Guse, t, seed, rf, yt, ut, 0, r, xin, xn, la1, h1, ln1);
-                if (i < N) {
-#pragma unroll
-                    for (int k = 0; k < NX; ++k) {
-                        x[r][k] = xn[0][k];
-                        st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xn[0][k]);
-                    }
-                    const double l1 = la1[0] + logw[r];   // src/PGAS.py:101-102
-                    lw[0][r] = l1;
-                    lw[1][r] = l1 + h1[0];                // :117-118
-                    ln[r] = ln1[0];
+                for (int k = 0; k < NX; ++k) {
+                    x[r][k] = xn[0][k];
+                    st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xn[0][k]);
                 }
-                sm.la[i] = la1[0];
+                const double l1 = la1[0] + logw[r];   // src/PGAS.py:101-102
+                lw[0][r] = l1;
+                lw[1][r] = l1 + h1[0];                // :117-118
             }
+            sm.la[i] = la1[0];
         }
         double S[2];
-        small_scan<2>(sm, lw, N, S);   // ends with a barrier: sm.num and sm.la are visible
+        small_scan<2, NR>(sm, lw, N, S);   // ends with a barrier: sm.num and sm.la are visible
         // ---- systematic resampling (src/Filtering.py:28-35) and the ancestor of the conditioned particle (src/PGAS.py:121-127)
-        const double u1 = u_res[t], u2 = u_anc[t];
         const bool valid1 = (S[0] > 0.0) && (S[0] < __builtin_inf()), valid2 = (S[1] > 0.0) && (S[1] < __builtin_inf());
-        const int cnt2 = small_count(sm, sm.num[1], u2 * S[1]);
+        const int cnt2 = small_count<NR>(sm, sm.num[1], u2 * S[1]);
         const int ref_idx = valid2 ? (cnt2 > N - 1 ? N - 1 : cnt2) : N - 1;
 #pragma unroll
-        for (int r = 0; r < PG_PPT; ++r) {
+        for (int r = 0; r < NR; ++r) {
             const int i = r * PG_BLK + tid;
-            if (r < nr && i < N) {
+            if (i < N) {
                 int a = i;   // no positive weight: identity (src/Filtering.py:25)
                 if (valid1) {
-                    const int p = small_lower_bound(sm.num[0], slot_U(u1, i, N, invN, pow2) * S[0]);
+                    const int p = small_lower_bound<NR * PG_BLK>(sm.num[0], slot_U(u1, i, N, invN, pow2) * S[0]);
                     a = p > N - 1 ? N - 1 : p;
                 }
                 if (i == N - 1) a = ref_idx;
-                st_stream(&anc_trace[(size_t)(t - 1) * N + i], (int32_t)a);
+                anc_trace[(size_t)(t - 1) * N + i] = (int32_t)a;   // plain store: the back-trace of this very launch reads it (L2)
                 logw[r] = ln[r] - sm.la[a];   // src/PGAS.py:137-147
                 if (logw_trace != nullptr) logw_trace[(size_t)t * N + i] = logw[r];
             }
@@ -1248,17 +1241,17 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
     }
 
     // ---- final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
-    double lwf[1][PG_PPT];
+    double lwf[1][NR];
 #pragma unroll
-    for (int r = 0; r < PG_PPT; ++r) {
+    for (int r = 0; r < NR; ++r) {
         const int i = r * PG_BLK + tid;
-        lwf[0][r] = (r < nr && i < N) ? logw[r] : -__builtin_inf();
-        if (r < nr && i < N) logw_last[i] = logw[r];
+        lwf[0][r] = i < N ? logw[r] : -__builtin_inf();
+        if (i < N) logw_last[i] = logw[r];
     }
     double Sf[1];
-    small_scan<1>(sm, lwf, N, Sf);
+    small_scan<1, NR>(sm, lwf, N, Sf);
     const bool validf = (Sf[0] > 0.0) && (Sf[0] < __builtin_inf());
-    const int cf = small_count(sm, sm.num[0], ld_const(&swp->u_final) * Sf[0]);
+    const int cf = small_count<NR>(sm, sm.num[0], ld_const(&swp->u_final) * Sf[0]);
     const int fidx = validf ? (cf > N - 1 ? N - 1 : cf) : N - 1;
     // the traces were written by every wave of this workgroup: make them visible to the one lane that chases
     __threadfence();
@@ -1266,6 +1259,244 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
     if (tid == 0) {
         hdr->final_idx = fidx;
         int b = fidx;
+#ifdef PG_SMALL_NO_BT
+        if (T > 0) return;
+#endif
+        for (int i = T - 1; i >= 0; --i) {
+#pragma unroll
+            for (int k = 0; k < NX; ++k) traj[(size_t)i * NX + k] = __hip_atomic_load(&x_trace[(size_t)i * row + (size_t)b * NX + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i > 0) b = __hip_atomic_load(&anc_trace[(size_t)(i - 1) * N + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep_pipe: the single-workgroup sweep for N <= 256 (the reference's N = 200) as a producer / consumer pipeline INSIDE the
+// workgroup -- the structure of the large sweep (section 3 of DESIGN.md) in miniature.  Quirk Q1 again: x_t[i] depends on x_{t-1}[i]
+// only, so four PRODUCER waves (one particle per lane) run the propagation ahead, step after step, and leave
+// (log p(y_t|aux_t), log N(ref_t; aux_t, S), log p(y_t|x_t)) of every particle in an LDS ring; ONE CONSUMER wave (four consecutive
+// particles per lane) runs the weight recursion -- both softmax scans, the resampling search, the ancestor draw, the weight update --
+// entirely with wave-level primitives: no workgroup barrier anywhere in the time loop, the two sides meet through two LDS flags.
+// k_sweep_small does the same work with every wave in lock step: per step the propagation's latency chain and the recursion's add up
+// (8.3 ms per sweep at N = 200, T = 2000); here they overlap.
+// ------------------------------------------------------------------------------------------
+#define PG_PIPE_RING 8
+#define PG_PIPE_N 256
+struct PipeSmem {
+    double ring[PG_PIPE_RING][3][PG_PIPE_N];   // per step: la, h, ln by particle
+    double num[2][PG_PIPE_N];                  // CDF numerators of the step the consumer is working on (+inf past N)
+    int ready[4];                              // producer wave w has finished step ready[w]
+    int done;                                  // the consumer has finished step `done`
+};
+
+__device__ __forceinline__ int pipe_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void pipe_publish(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// consumer wave: fixed-point CDFs of NW weight vectors, lane l holding particles 4 l .. 4 l + 3 (consecutive: the prefix sums need no
+// transposition); numerators to registers (and, for the searched vector, to LDS), S per vector
+template <int NW>
+__device__ __forceinline__ void pipe_scan(const double (&lw)[NW][4], int n, double (&num)[NW][4], double (&S)[NW]) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        double m = __builtin_fmax(__builtin_fmax(lw[w][0], lw[w][1]), __builtin_fmax(lw[w][2], lw[w][3]));
+        m = wave_max(m);
+        const double kref = pgas_seg_ref(m);
+        double arg[4];
+        uint64_t qv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) arg[j] = pgas_seg_arg(lw[w][j], kref);
+        dev_exp_q51_n<4>(arg, qv);
+        uint64_t loc[4], run = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            run += qv[j];
+            loc[j] = run;
+        }
+        const uint64_t incl = wave_incl_scan_u64(run);
+        const uint64_t base = incl - run;
+        const uint64_t tot = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(incl >> 32), 63) << 32) |
+                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)incl, 63);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) num[w][j] = (4 * lane + j < n) ? pgas_u64_to_double(base + loc[j]) * PGAS_FIX_INV : __builtin_inf();
+        S[w] = pgas_u64_to_double(tot) * PGAS_FIX_INV;
+    }
+}
+
+template <int NX, int D, int JIN, int J0T>
+__global__ __launch_bounds__(320) void k_sweep_pipe(DevModel md, const TransParams* __restrict__ tpp, const double* __restrict__ G_arg,
+                                                    const SweepParams* __restrict__ swp, const double* __restrict__ u_res,
+                                                    const double* __restrict__ u_anc, const double* __restrict__ m0L0,
+                                                    const double* __restrict__ ref, double* __restrict__ x_trace,
+                                                    int32_t* __restrict__ anc_trace, double* __restrict__ logw_last,
+                                                    double* __restrict__ logw_trace /* (T, N) or NULL */, UpperHdr* __restrict__ hdr,
+                                                    double* __restrict__ traj) {
+    __shared__ PipeSmem sm;
+    extern __shared__ __attribute__((aligned(16))) double pg_g_lds_pipe[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int N = md.N, T = md.T;
+    const size_t row = (size_t)N * NX;
+    {
+        int gtot = NX;
+#pragma unroll
+        for (int d = 0; d < D; ++d) gtot *= (d == D - 1 && D > 1) ? JIN : md.J[d];
+        for (int i = tid; i < gtot; i += 320) pg_g_lds_pipe[i] = G_arg[i];
+        if (tid < 4) sm.ready[tid] = 0;
+        if (tid == 4) sm.done = 0;
+        __syncthreads();   // the only workgroup barrier of the kernel
+    }
+    const uint64_t seed = ld_const(&swp->seed);
+    if (wave < 4) {
+        // ================= producers: particle i = tid through every time step (src/PGAS.py:45-77,130-134)
+        TransParams tp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tp.LS[q] = ld_const(&tpp->LS[q]);
+            tp.LSinv[q] = ld_const(&tpp->LSinv[q]);
+        }
+        tp.cS = ld_const(&tpp->cS);
+        tp.G = G_arg;
+        const int i = tid;
+        double x[1][NX];
+        {
+            double z[2];
+            pgas_rng_normals(seed, PGAS_STREAM_INIT, 0u, (uint64_t)(i < N ? i : N - 1), NX, z);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                double v = m0L0[k];
+#pragma unroll
+                for (int l = 0; l <= k; ++l) v = PGAS_FMA(m0L0[NX + k * NX + l], z[l], v);
+                x[0][k] = (i == N - 1) ? ref[k] : v;
+                if (i < N) x_trace[(size_t)i * NX + k] = x[0][k];
+            }
+        }
+        for (int t = 1; t < T; ++t) {
+            while (pipe_flag(&sm.done) < t - PG_PIPE_RING) __builtin_amdgcn_s_sleep(1);   // the ring slot of step t is free again
+            const double* __restrict__ yt = md.y + (size_t)t * md.ny;
+            const double* __restrict__ ut = md.u + (size_t)t * md.nu;
+            double rf[NX];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) rf[k] = ref[(size_t)t * NX + k];
+            double xn[1][NX], la1[1], h1[1], ln1[1];
+            propagate_group<NX, D, JIN, 1, J0T>(md, tp, pg_g_lds_pipe, t, seed, rf, yt, ut, 0, 0, x, xn, la1, h1, ln1);
+            double (&slot)[3][PG_PIPE_N] = sm.ring[t & (PG_PIPE_RING - 1)];
+            slot[0][i] = la1[0];
+            slot[1][i] = h1[0];
+            slot[2][i] = ln1[0];
+            if (i < N) {
+#pragma unroll
+                for (int k = 0; k < NX; ++k) {
+                    x[0][k] = xn[0][k];
+                    st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xn[0][k]);
+                }
+            }
+            pipe_publish(&sm.ready[wave], t);   // release: the slot's values are in LDS before the flag is
+        }
+        __threadfence();                       // the state trace is in memory before the consumer chases ancestors through it
+        pipe_publish(&sm.ready[wave], T);
+        return;
+    }
+    // ================= consumer: the weight recursion (src/PGAS.py:90-127,137-147), particles 4 lane .. 4 lane + 3
+    const bool pow2 = (N & (N - 1)) == 0;
+    const double invN = 1.0 / (double)N;
+    double logw[4] = {0.0, 0.0, 0.0, 0.0};
+    if (logw_trace != nullptr) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (4 * lane + j < N) logw_trace[4 * lane + j] = 0.0;
+    }
+    for (int t = 1; t < T; ++t) {
+        const double u1 = u_res[t], u2 = u_anc[t];
+        for (;;) {
+            const int r = lane < 4 ? pipe_flag(&sm.ready[lane]) : T;
+            if (__ballot(r < t) == 0ull) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const double (&slot)[3][PG_PIPE_N] = sm.ring[t & (PG_PIPE_RING - 1)];
+        double lw[2][4], ln[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * lane + j;
+            const double l1 = slot[0][i] + logw[j];   // src/PGAS.py:101-102
+            lw[0][j] = i < N ? l1 : -__builtin_inf();
+            lw[1][j] = i < N ? l1 + slot[1][i] : -__builtin_inf();   // :117-118
+            ln[j] = slot[2][i];
+        }
+        double num[2][4], S[2];
+        pipe_scan<2>(lw, N, num, S);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sm.num[0][4 * lane + j] = num[0][j];
+        const bool valid1 = (S[0] > 0.0) && (S[0] < __builtin_inf()), valid2 = (S[1] > 0.0) && (S[1] < __builtin_inf());
+        // ancestor of the conditioned particle (src/PGAS.py:121-127): a count against this lane's own numerators
+        const double tau2 = u2 * S[1];
+        int c2 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c2 += (num[1][j] < tau2) ? 1 : 0;
+        c2 = wave_sum_i(c2);
+        const int ref_idx = valid2 ? (c2 > N - 1 ? N - 1 : c2) : N - 1;
+        // systematic resampling (src/Filtering.py:28-35): four slots per lane, four independent lower-bound chains
+        int a[4];
+        double tau[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tau[j] = slot_U(u1, 4 * lane + j, N, invN, pow2) * S[0];
+        {
+            int p[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int step = PG_PIPE_N / 2; step >= 1; step >>= 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double v = sm.num[0][p[j] + step - 1];
+                    p[j] = (v < tau[j]) ? p[j] + step : p[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = 4 * lane + j;
+                const int pj = (sm.num[0][p[j]] < tau[j]) ? p[j] + 1 : p[j];
+                a[j] = valid1 ? (pj > N - 1 ? N - 1 : pj) : (i < N ? i : N - 1);
+                if (i == N - 1) a[j] = ref_idx;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = 4 * lane + j;
+            const double lav = slot[0][a[j]];
+            if (i < N) {
+                anc_trace[(size_t)(t - 1) * N + i] = (int32_t)a[j];   // plain store: the back-trace of this very launch reads it (L2)
+                logw[j] = ln[j] - lav;   // src/PGAS.py:137-147
+                if (logw_trace != nullptr) logw_trace[(size_t)t * N + i] = logw[j];
+            }
+        }
+        pipe_publish(&sm.done, t);   // the slot of step t may be overwritten (the reads above are complete: release)
+    }
+    // ---- final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
+    double lwf[1][4], numf[1][4], Sf[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = 4 * lane + j;
+        lwf[0][j] = i < N ? logw[j] : -__builtin_inf();
+        if (i < N) logw_last[i] = logw[j];
+    }
+    pipe_scan<1>(lwf, N, numf, Sf);
+    const double tauf = ld_const(&swp->u_final) * Sf[0];
+    int cf = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) cf += (numf[0][j] < tauf) ? 1 : 0;
+    cf = wave_sum_i(cf);
+    const bool validf = (Sf[0] > 0.0) && (Sf[0] < __builtin_inf());
+    const int fidx = validf ? (cf > N - 1 ? N - 1 : cf) : N - 1;
+    for (;;) {   // every producer has written and fenced its part of the state trace
+        const int r = lane < 4 ? pipe_flag(&sm.ready[lane]) : T;
+        if (__ballot(r < T) == 0ull) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __threadfence();   // this wave's own ancestor stores
+    if (lane == 0) {
+        hdr->final_idx = fidx;
+        int b = fidx;
+#ifdef PG_SMALL_NO_BT
+        if (T > 0) return;
+#endif
         for (int i = T - 1; i >= 0; --i) {
 #pragma unroll
             for (int k = 0; k < NX; ++k) traj[(size_t)i * NX + k] = __hip_atomic_load(&x_trace[(size_t)i * row + (size_t)b * NX + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
