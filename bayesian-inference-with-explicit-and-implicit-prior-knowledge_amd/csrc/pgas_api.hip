@@ -97,7 +97,7 @@ typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, Peers, i
 typedef void (*init_fn)(DevModel, uint64_t, const SweepParams*, const double*, const double*, double*);
 typedef void (*basis_fn)(DevModel, const int32_t*, const double*, int64_t, int, double*);
 typedef void (*small_fn)(DevModel, const TransParams*, const double*, const SweepParams*, const double*, const double*, const double*, const double*, double*, int32_t*,
-                         double*, double*, UpperHdr*, double*);
+                         double*, double*, UpperHdr*, double*, const double*);
 
 struct Variant {
     front_fn front;
@@ -212,6 +212,7 @@ struct pgas_ctx {
     int last_graph = 0;            // 1: the last pgas_sweep replayed the captured graph
     int use_small = 1;             // PGAS_OPT_SMALL_SWEEP: contexts of at most one segment run the whole sweep in one workgroup (k_sweep_small)
     int last_small = 0;            // 1: the last pgas_sweep did
+    double* d_znoise = nullptr;    // (T, N, 2) propagation noise of a single-workgroup sweep (k_small_noise)
     int graph_failed = 0;          // capture or instantiation failed once: stay on the eager path
     hipStream_t sG = nullptr;      // the stream captured sweeps are recorded on and replayed on (the caller's may be the legacy default
                                    // stream, which cannot be captured); ordered against the caller's stream with ev_g0 / ev_g1
@@ -471,6 +472,7 @@ void pgas_destroy(pgas_ctx* c) {
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
     if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
     if (c->sG) (void)hipStreamDestroy(c->sG);
+    hipFree(c->d_znoise);
     hipFree(c->d_tp); hipFree(c->d_sp); hipFree(c->d_ures); hipFree(c->d_uanc); hipFree(c->d_refbuf); hipFree(c->d_trajbuf);
     hipFree(c->d_G); hipFree(c->logw_last); hipFree(c->logw_trace); hipFree(c->d_bt);
     for (RowStore& r : c->rs) r.release();
@@ -1059,12 +1061,18 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
         // at most one segment of particles: the whole sweep -- x_0, T-1 steps, final index, back-trace -- is ONE launch of ONE workgroup
         rc = sweep_begin(c, seed, st);
         if (rc) return rc;
+        if (!c->d_znoise) HIPCHK(c, hipMalloc(&c->d_znoise, (size_t)T * N * 2 * sizeof(double)));
+        if (T > 1) {
+            const int64_t nz = (int64_t)N * (T - 1);
+            hipLaunchKernelGGL(k_small_noise, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, (const SweepParams*)c->d_sp, md.p0, N, T, c->d_znoise);
+            KCHK(c, "k_small_noise");
+        }
         const size_t lds = (size_t)c->gtotal * sizeof(double);   // the coefficient tensor, beside 41 KB of static LDS
         if (lds > 64 * 1024) FAIL(c, PGAS_E_ARG, "k_sweep_small: coefficient tensor of %zu bytes does not fit the LDS budget", lds);
         const bool pipe = N <= PG_PIPE_N && c->use_small == 1;   // PGAS_OPT_SMALL_SWEEP = 2: the lock-step kernel at every N <= 1024
         hipLaunchKernelGGL(pipe ? c->var.pipe : c->var.small[N <= PG_BLK ? 0 : (N <= 2 * PG_BLK ? 1 : 2)], dim3(1), dim3(pipe ? 320 : PG_BLK), lds, st, md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp,
                            (const double*)c->d_ures, (const double*)c->d_uanc, (const double*)c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].blk[0],
-                           (int32_t*)c->rs[PG_RB_ANC].blk[0], c->logw_last, c->logw_trace, c->sb[T & 1].hdr, traj_dev);
+                           (int32_t*)c->rs[PG_RB_ANC].blk[0], c->logw_last, c->logw_trace, c->sb[T & 1].hdr, traj_dev, (const double*)c->d_znoise);
         KCHK(c, "k_sweep_small");
         c->last_small = 1;
         c->last_chunk = 1;

@@ -372,7 +372,10 @@ __device__ __forceinline__ void cheb_next(Cheb& c) {
 // dense frequency grid; the coefficients are wave-uniform (scalar loads), the outer dimensions'
 // sines come from a recurrence, only the innermost dimension's table lives in registers.
 // ------------------------------------------------------------------------------------------
-template <int NX, int D, int JIN, int P, int J0T = 0>
+// WIDE (k_sweep_pipe: one wave per SIMD, the coefficients in LDS, registers to spare): the rows of the 2-D FAST contraction fully
+// unrolled, so that the seven row sums are independent instruction streams instead of one rolled, latency-bound loop.  Every
+// accumulation keeps its order (q ascending inside a row, a ascending across rows): the same bits.
+template <int NX, int D, int JIN, int P, int J0T = 0, bool WIDE = false>
 __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __restrict__ G, const double* __restrict__ ut,
                                           const double (&x)[P][NX], double (&aux)[P][NX]) {
     constexpr bool FAST = J0T > 0;
@@ -449,7 +452,32 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
                     cheb_next(c0[p]);
                 }
             };
-            if constexpr (FAST) {
+            if constexpr (FAST && WIDE) {
+                double in[J0T][P][NX];
+#pragma unroll
+                for (int a = 0; a < J0T; ++a) {
+                    const double* __restrict__ Ga = G + (size_t)a * JIN * NX;
+#pragma unroll
+                    for (int p = 0; p < P; ++p)
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) in[a][p][k] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < JIN; ++q)
+#pragma unroll
+                        for (int k = 0; k < NX; ++k)
+#pragma unroll
+                            for (int p = 0; p < P; ++p) in[a][p][k] = PGAS_FMA(Ga[q * NX + k], tab[p][q], in[a][p][k]);
+                }
+#pragma unroll
+                for (int a = 0; a < J0T; ++a) {
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+#pragma unroll
+                        for (int k = 0; k < NX; ++k) aux[p][k] = PGAS_FMA(c0[p].cur, in[a][p][k], aux[p][k]);
+                        cheb_next(c0[p]);
+                    }
+                }
+            } else if constexpr (FAST) {
                 // Kept rolled (unrolled, the compiler hoists all J0T x JIN x NX coefficient loads to the top and spills ~290 SGPRs)
                 // and software-pipelined by hand: the scalar loads of row a + 1 are issued before the FMAs of row a, so their
                 // latency hides under 38 vector instructions instead of stalling every iteration.

@@ -1031,6 +1031,52 @@ __global__ void k_detmath(int which, const double* __restrict__ x, const double*
 //   num_k = c_k 2^-51,   S = s 2^-51   (c_k the integer cumsum, s its total)
 // and the systematic-resampling search, the ancestor draw and the final index are counts #{k : num_k < tau} against that.
 // ------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS only: __syncthreads() also waits for the wave's outstanding global stores (vmcnt(0)), which in the
+// single-workgroup sweeps are the trace rows on their way to HBM -- a microsecond per step that nothing in the workgroup waits for.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The propagation noise of a whole small sweep (src/PGAS.py:72-75), one Philox block + Box-Muller pair per (t, particle), written
+// by a grid-wide launch BEFORE the single-workgroup sweep: generated by the lane that owns the particle, in sequence with everything
+// else, it is two thirds of the step's latency chain at one wave per SIMD (6 700 of 10 200 cycles, measured); generated ahead by
+// noise waves inside the workgroup, the waves got in each other's way (14.5 ms per sweep).  T x N x 16 bytes: 6.4 MB at N = 200.
+__global__ __launch_bounds__(256) void k_small_noise(const SweepParams* __restrict__ swp, int64_t p0, int N, int T, double* __restrict__ znoise) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= (int64_t)N * (T - 1)) return;
+    const int t = 1 + (int)(q / N), i = (int)(q % N);
+    double z0, z1;
+    pgas_normal_pair(pgas_rng_block(ld_const(&swp->seed), PGAS_STREAM_PROP, 0u, (uint32_t)t, (uint64_t)(p0 + i)), &z0, &z1);
+    znoise[((size_t)t * N + i) * 2] = z0;
+    znoise[((size_t)t * N + i) * 2 + 1] = z1;
+}
+
+// one particle through one time step given its noise: transition mean (WIDE: rows of the contraction unrolled), new state, the three
+// log-densities -- propagate_group's arithmetic (src/PGAS.py:45-77,90-100,109-116,130-145)
+template <int NX, int D, int JIN, int J0T>
+__device__ __forceinline__ void small_particle_step(const DevModel& md, const TransParams& tp, const double* __restrict__ G, const double* __restrict__ ut,
+                                                    const double* __restrict__ yt, const double (&rf)[NX], bool conditioned, const double (&xin)[1][NX],
+                                                    const double (&z)[2], double (&xt)[NX], double& la, double& h, double& ln) {
+    double aux[1][NX];
+    eval_mean<NX, D, JIN, 1, J0T, true>(md, G, ut, xin, aux);
+    la = loglik<NX>(md, yt, aux[0]);
+    double quad = 0.0;
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        double w = 0.0;
+#pragma unroll
+        for (int l = 0; l <= k; ++l) w = PGAS_FMA(tp.LSinv[k * NX + l], rf[l] - aux[0][l], w);
+        quad = PGAS_FMA(w, w, quad);
+    }
+    h = PGAS_FMA(-0.5, quad, tp.cS);
+#pragma unroll
+    for (int k = 0; k < NX; ++k) {
+        double v = aux[0][k];
+#pragma unroll
+        for (int l = 0; l <= k; ++l) v = PGAS_FMA(tp.LS[k * NX + l], z[l], v);
+        xt[k] = conditioned ? rf[k] : v;
+    }
+    ln = loglik<NX>(md, yt, xt);
+}
+
 struct SmallSmem {
     uint64_t q[2][PGAS_SEG];     // numerators in particle order (transposition for the prefix sums)
     double num[2][PGAS_SEG];     // CDF numerators of the resampling / ancestor weights, +inf past N
@@ -1053,7 +1099,7 @@ __device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW]
         m = wave_max(m);
         if (lane == 0) sm.red[w][wave] = m;
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         double m = sm.red[w][0];
@@ -1068,7 +1114,7 @@ __device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW]
 #pragma unroll
         for (int r = 0; r < NR; ++r) sm.q[w][r * PG_BLK + tid] = qv[r];
     }
-    __syncthreads();
+    lds_barrier();
     uint64_t loc[NW][NR], incl[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
@@ -1081,7 +1127,7 @@ __device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW]
         incl[w] = wave_incl_scan_u64(run);
         if (lane == 63) sm.wtot[w][wave] = incl[w];
     }
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         uint64_t off = 0, tot = 0;
@@ -1099,7 +1145,7 @@ __device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW]
         }
         S[w] = pgas_u64_to_double(tot) * PGAS_FIX_INV;
     }
-    __syncthreads();
+    lds_barrier();
 }
 
 // #{k < span : num[k] < tau} over the +inf padded segment (branch-free lower bound; span = NR * 256, a power of two)
@@ -1121,11 +1167,11 @@ __device__ __forceinline__ int small_count(SmallSmem& sm, const double* __restri
     for (int j = 0; j < NR; ++j) k += (num[j * PG_BLK + tid] < tau) ? 1 : 0;
     k = wave_sum_i(k);
     if (lane == 0) sm.cnt[wave] = k;
-    __syncthreads();
+    lds_barrier();
     int tot = 0;
 #pragma unroll
     for (int v = 0; v < PG_BLK / 64; ++v) tot += sm.cnt[v];
-    __syncthreads();
+    lds_barrier();
     return tot;
 }
 
@@ -1136,7 +1182,7 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
                                                         const double* __restrict__ ref, double* __restrict__ x_trace,
                                                         int32_t* __restrict__ anc_trace, double* __restrict__ logw_last,
                                                         double* __restrict__ logw_trace /* (T, N) or NULL */, UpperHdr* __restrict__ hdr,
-                                                        double* __restrict__ traj) {
+                                                        double* __restrict__ traj, const double* __restrict__ znoise /* (T, N, 2): k_small_noise */) {
     __shared__ SmallSmem sm;
     extern __shared__ __attribute__((aligned(16))) double pg_g_lds_small[];   // the coefficient tensor (every basis shape: one wave per SIMD
                                                                                // has nothing to hide a scalar load per grid row behind)
@@ -1157,7 +1203,7 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
 #pragma unroll
         for (int d = 0; d < D; ++d) gtot *= (d == D - 1 && D > 1) ? JIN : md.J[d];
         for (int i = tid; i < gtot; i += PG_BLK) pg_g_lds_small[i] = G_arg[i];
-        __syncthreads();
+        lds_barrier();
     }
     const double* Guse = pg_g_lds_small;
     const bool pow2 = (N & (N - 1)) == 0;
@@ -1185,36 +1231,58 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
         }
     }
 
-    // ---- the time loop (src/PGAS.py:199-221)
-    for (int t = 1; t < T; ++t) {
-        const double* __restrict__ yt = md.y + (size_t)t * md.ny;
-        const double* __restrict__ ut = md.u + (size_t)t * md.nu;
-        double rf[NX];
+    // ---- the time loop (src/PGAS.py:199-221).  y_t, ref_t, the uniforms and the particles' noise are fetched one step ahead.
+    double yn[PGAS_MAX_NY], rn[NX], u1n = 0.0, u2n = 0.0;
+    double2 zn[NR];
+    auto fetch = [&](int t) {
 #pragma unroll
-        for (int k = 0; k < NX; ++k) rf[k] = ref[(size_t)t * NX + k];
-        const double u1 = u_res[t], u2 = u_anc[t];
+        for (int k = 0; k < PGAS_MAX_NY; ++k) yn[k] = k < md.ny ? md.y[(size_t)t * md.ny + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < NX; ++k) rn[k] = ref[(size_t)t * NX + k];
+        u1n = u_res[t];
+        u2n = u_anc[t];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = r * PG_BLK + tid;
+            zn[r] = reinterpret_cast<const double2*>(znoise)[(size_t)t * N + (i < N ? i : N - 1)];
+        }
+    };
+    if (T > 1) fetch(1);
+    for (int t = 1; t < T; ++t) {
+        const double* __restrict__ ut = md.u + (size_t)t * md.nu;
+        double yt[PGAS_MAX_NY], rf[NX];
+#pragma unroll
+        for (int k = 0; k < PGAS_MAX_NY; ++k) yt[k] = yn[k];
+#pragma unroll
+        for (int k = 0; k < NX; ++k) rf[k] = rn[k];
+        const double u1 = u1n, u2 = u2n;
+        double2 zc[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) zc[r] = zn[r];
+        fetch(t + 1 < T ? t + 1 : t);
         double lw[2][NR], ln[NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int i = r * PG_BLK + tid;
-            double xin[1][NX], xn[1][NX], la1[1], h1[1], ln1[1];
+            double xin[1][NX], xt[NX], la1, h1, ln1;
 #pragma unroll
             for (int k = 0; k < NX; ++k) xin[0][k] = x[r][k];
-            propagate_group<NX, D, JIN, 1, J0T>(md, tp, Guse, t, seed, rf, yt, ut, 0, r, xin, xn, la1, h1, ln1);
+            const double z[2] = {zc[r].x, zc[r].y};
+            small_particle_step<NX, D, JIN, J0T>(md, tp, Guse, ut, yt, rf, md.p0 + i == md.Ng - 1, xin, z, xt, la1, h1, ln1);
             lw[0][r] = -__builtin_inf();
             lw[1][r] = -__builtin_inf();
-            ln[r] = ln1[0];
+            ln[r] = ln1;
             if (i < N) {
 #pragma unroll
                 for (int k = 0; k < NX; ++k) {
-                    x[r][k] = xn[0][k];
-                    st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xn[0][k]);
+                    x[r][k] = xt[k];
+                    st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xt[k]);
                 }
-                const double l1 = la1[0] + logw[r];   // src/PGAS.py:101-102
+                const double l1 = la1 + logw[r];   // src/PGAS.py:101-102
                 lw[0][r] = l1;
-                lw[1][r] = l1 + h1[0];                // :117-118
+                lw[1][r] = l1 + h1;                // :117-118
             }
-            sm.la[i] = la1[0];
+            sm.la[i] = la1;
         }
         double S[2];
         small_scan<2, NR>(sm, lw, N, S);   // ends with a barrier: sm.num and sm.la are visible
@@ -1237,7 +1305,7 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
                 if (logw_trace != nullptr) logw_trace[(size_t)t * N + i] = logw[r];
             }
         }
-        __syncthreads();   // sm.la / sm.num are rewritten by the next step
+        lds_barrier();   // sm.la / sm.num are rewritten by the next step
     }
 
     // ---- final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
@@ -1255,7 +1323,7 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
     const int fidx = validf ? (cf > N - 1 ? N - 1 : cf) : N - 1;
     // the traces were written by every wave of this workgroup: make them visible to the one lane that chases
     __threadfence();
-    __syncthreads();
+    lds_barrier();
     if (tid == 0) {
         hdr->final_idx = fidx;
         int b = fidx;
@@ -1289,8 +1357,19 @@ struct PipeSmem {
     int done;                                  // the consumer has finished step `done`
 };
 
-__device__ __forceinline__ int pipe_flag(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void pipe_publish(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// Flags between the waves of the workgroup, in LDS.  Release = this wave's LDS operations have completed (lgkmcnt) before the flag is
+// written; acquire = LDS reads after the flag read are issued after it (LDS executes a wave's operations in order).  NOT the
+// compiler's release / acquire: those also wait for the wave's outstanding GLOBAL stores (vmcnt(0)) -- the trace rows on their way to
+// HBM, a microsecond per step that nothing in the workgroup depends on.
+__device__ __forceinline__ int pipe_flag(const int* p) {
+    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    asm volatile("" ::: "memory");
+    return v;
+}
+__device__ __forceinline__ void pipe_publish(int* p, int v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 
 // consumer wave: fixed-point CDFs of NW weight vectors, lane l holding particles 4 l .. 4 l + 3 (consecutive: the prefix sums need no
 // transposition); numerators to registers (and, for the searched vector, to LDS), S per vector
@@ -1330,7 +1409,7 @@ __global__ __launch_bounds__(320) void k_sweep_pipe(DevModel md, const TransPara
                                                     const double* __restrict__ ref, double* __restrict__ x_trace,
                                                     int32_t* __restrict__ anc_trace, double* __restrict__ logw_last,
                                                     double* __restrict__ logw_trace /* (T, N) or NULL */, UpperHdr* __restrict__ hdr,
-                                                    double* __restrict__ traj) {
+                                                    double* __restrict__ traj, const double* __restrict__ znoise /* (T, N, 2): k_small_noise */) {
     __shared__ PipeSmem sm;
     extern __shared__ __attribute__((aligned(16))) double pg_g_lds_pipe[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1343,7 +1422,7 @@ __global__ __launch_bounds__(320) void k_sweep_pipe(DevModel md, const TransPara
         for (int i = tid; i < gtot; i += 320) pg_g_lds_pipe[i] = G_arg[i];
         if (tid < 4) sm.ready[tid] = 0;
         if (tid == 4) sm.done = 0;
-        __syncthreads();   // the only workgroup barrier of the kernel
+        lds_barrier();   // the only workgroup barrier of the kernel
     }
     const uint64_t seed = ld_const(&swp->seed);
     if (wave < 4) {
@@ -1370,24 +1449,38 @@ __global__ __launch_bounds__(320) void k_sweep_pipe(DevModel md, const TransPara
                 if (i < N) x_trace[(size_t)i * NX + k] = x[0][k];
             }
         }
-        for (int t = 1; t < T; ++t) {
-            while (pipe_flag(&sm.done) < t - PG_PIPE_RING) __builtin_amdgcn_s_sleep(1);   // the ring slot of step t is free again
-            const double* __restrict__ yt = md.y + (size_t)t * md.ny;
-            const double* __restrict__ ut = md.u + (size_t)t * md.nu;
-            double rf[NX];
+        // y_t, ref_t and the particle's noise are fetched one step ahead
+        double yn[PGAS_MAX_NY], rn[NX];
+        double2 zn = make_double2(0.0, 0.0);
+        auto fetch = [&](int t) {
 #pragma unroll
-            for (int k = 0; k < NX; ++k) rf[k] = ref[(size_t)t * NX + k];
-            double xn[1][NX], la1[1], h1[1], ln1[1];
-            propagate_group<NX, D, JIN, 1, J0T>(md, tp, pg_g_lds_pipe, t, seed, rf, yt, ut, 0, 0, x, xn, la1, h1, ln1);
+            for (int k = 0; k < PGAS_MAX_NY; ++k) yn[k] = k < md.ny ? md.y[(size_t)t * md.ny + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) rn[k] = ref[(size_t)t * NX + k];
+            zn = reinterpret_cast<const double2*>(znoise)[(size_t)t * N + (i < N ? i : N - 1)];
+        };
+        if (T > 1) fetch(1);
+        for (int t = 1; t < T; ++t) {
+            const double* __restrict__ ut = md.u + (size_t)t * md.nu;
+            double yt[PGAS_MAX_NY], rf[NX];
+#pragma unroll
+            for (int k = 0; k < PGAS_MAX_NY; ++k) yt[k] = yn[k];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) rf[k] = rn[k];
+            const double z[2] = {zn.x, zn.y};
+            fetch(t + 1 < T ? t + 1 : t);
+            double xt[NX], la1, h1, ln1;
+            small_particle_step<NX, D, JIN, J0T>(md, tp, pg_g_lds_pipe, ut, yt, rf, md.p0 + i == md.Ng - 1, x, z, xt, la1, h1, ln1);
+            while (pipe_flag(&sm.done) < t - PG_PIPE_RING) __builtin_amdgcn_s_sleep(1);   // the ring slot of step t is free again
             double (&slot)[3][PG_PIPE_N] = sm.ring[t & (PG_PIPE_RING - 1)];
-            slot[0][i] = la1[0];
-            slot[1][i] = h1[0];
-            slot[2][i] = ln1[0];
+            slot[0][i] = la1;
+            slot[1][i] = h1;
+            slot[2][i] = ln1;
             if (i < N) {
 #pragma unroll
                 for (int k = 0; k < NX; ++k) {
-                    x[0][k] = xn[0][k];
-                    st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xn[0][k]);
+                    x[0][k] = xt[k];
+                    st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xt[k]);
                 }
             }
             pipe_publish(&sm.ready[wave], t);   // release: the slot's values are in LDS before the flag is
@@ -1405,8 +1498,15 @@ __global__ __launch_bounds__(320) void k_sweep_pipe(DevModel md, const TransPara
         for (int j = 0; j < 4; ++j)
             if (4 * lane + j < N) logw_trace[4 * lane + j] = 0.0;
     }
+    double u1n = T > 1 ? u_res[1] : 0.0, u2n = T > 1 ? u_anc[1] : 0.0;
     for (int t = 1; t < T; ++t) {
-        const double u1 = u_res[t], u2 = u_anc[t];
+        const double u1 = u1n, u2 = u2n;
+        u1n = u_res[t + 1 < T ? t + 1 : t];   // next step's uniforms, requested early
+        u2n = u_anc[t + 1 < T ? t + 1 : t];
+        // the data-independent half of the thresholds first (a division when N is no power of two)
+        double U[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) U[j] = slot_U(u1, 4 * lane + j, N, invN, pow2);
         for (;;) {
             const int r = lane < 4 ? pipe_flag(&sm.ready[lane]) : T;
             if (__ballot(r < t) == 0ull) break;
@@ -1438,7 +1538,7 @@ __global__ __launch_bounds__(320) void k_sweep_pipe(DevModel md, const TransPara
         int a[4];
         double tau[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tau[j] = slot_U(u1, 4 * lane + j, N, invN, pow2) * S[0];
+        for (int j = 0; j < 4; ++j) tau[j] = U[j] * S[0];
         {
             int p[4] = {0, 0, 0, 0};
 #pragma unroll
