@@ -107,14 +107,13 @@ struct Variant {
     int P, W;   // particles per basis pass, waves per SIMD the k_propagate instantiation is built for
     int PPT;    // particles per thread of k_propagate: its grid is ceil(nseg / (PPT / 4))
     small_fn small[3];   // the whole sweep in one workgroup (N <= 256, 512, 1024: one, two, four particles per thread)
-    small_fn pipe;       // ... as a producer / consumer pipeline inside the workgroup (N <= 256)
 };
 
 template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT>
 Variant make_variant() {
     const prop_fn one = k_propagate<NX, D, JIN, P, W, J0T, PPT, true>;
     return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W, J0T, PPT>, one, k_aux<NX, D, JIN, P>, P, W, PPT,
-                   {k_sweep_small<NX, D, JIN, J0T, 1>, k_sweep_small<NX, D, JIN, J0T, 2>, k_sweep_small<NX, D, JIN, J0T, 4>}, k_sweep_pipe<NX, D, JIN, J0T>};
+                   {k_sweep_small<NX, D, JIN, J0T, 1>, k_sweep_small<NX, D, JIN, J0T, 2>, k_sweep_small<NX, D, JIN, J0T, 4>}};
 }
 
 // (nx, D, padded innermost extent) -> kernel instantiation <NX, D, JIN, P particles per basis pass, W waves/SIMD>
@@ -1069,8 +1068,7 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
         }
         const size_t lds = (size_t)c->gtotal * sizeof(double);   // the coefficient tensor, beside 41 KB of static LDS
         if (lds > 64 * 1024) FAIL(c, PGAS_E_ARG, "k_sweep_small: coefficient tensor of %zu bytes does not fit the LDS budget", lds);
-        const bool pipe = N <= PG_PIPE_N && c->use_small == 1;   // PGAS_OPT_SMALL_SWEEP = 2: the lock-step kernel at every N <= 1024
-        hipLaunchKernelGGL(pipe ? c->var.pipe : c->var.small[N <= PG_BLK ? 0 : (N <= 2 * PG_BLK ? 1 : 2)], dim3(1), dim3(pipe ? 320 : PG_BLK), lds, st, md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp,
+        hipLaunchKernelGGL(c->var.small[N <= PG_BLK ? 0 : (N <= 2 * PG_BLK ? 1 : 2)], dim3(1), dim3(PG_BLK), lds, st, md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp,
                            (const double*)c->d_ures, (const double*)c->d_uanc, (const double*)c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].blk[0],
                            (int32_t*)c->rs[PG_RB_ANC].blk[0], c->logw_last, c->logw_trace, c->sb[T & 1].hdr, traj_dev, (const double*)c->d_znoise);
         KCHK(c, "k_sweep_small");
@@ -1204,8 +1202,7 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         return PGAS_OK;
     }
     if (option == PGAS_OPT_SMALL_SWEEP) {
-        if (value < 0 || value > 2) FAIL(c, PGAS_E_ARG, "pgas_set_option: PGAS_OPT_SMALL_SWEEP takes 0, 1 or 2");
-        c->use_small = (int)value;
+        c->use_small = value ? 1 : 0;
         return PGAS_OK;
     }
     if (option == PGAS_OPT_GRAPH) {

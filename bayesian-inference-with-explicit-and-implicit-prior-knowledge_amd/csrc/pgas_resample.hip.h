@@ -1337,270 +1337,3 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
         }
     }
 }
-
-// ------------------------------------------------------------------------------------------
-// k_sweep_pipe: the single-workgroup sweep for N <= 256 (the reference's N = 200) as a producer / consumer pipeline INSIDE the
-// workgroup -- the structure of the large sweep (section 3 of DESIGN.md) in miniature.  Quirk Q1 again: x_t[i] depends on x_{t-1}[i]
-// only, so four PRODUCER waves (one particle per lane) run the propagation ahead, step after step, and leave
-// (log p(y_t|aux_t), log N(ref_t; aux_t, S), log p(y_t|x_t)) of every particle in an LDS ring; ONE CONSUMER wave (four consecutive
-// particles per lane) runs the weight recursion -- both softmax scans, the resampling search, the ancestor draw, the weight update --
-// entirely with wave-level primitives: no workgroup barrier anywhere in the time loop, the two sides meet through two LDS flags.
-// k_sweep_small does the same work with every wave in lock step: per step the propagation's latency chain and the recursion's add up
-// (8.3 ms per sweep at N = 200, T = 2000); here they overlap.
-// ------------------------------------------------------------------------------------------
-#define PG_PIPE_RING 8
-#define PG_PIPE_N 256
-struct PipeSmem {
-    double ring[PG_PIPE_RING][3][PG_PIPE_N];   // per step: la, h, ln by particle
-    double num[2][PG_PIPE_N];                  // CDF numerators of the step the consumer is working on (+inf past N)
-    int ready[4];                              // producer wave w has finished step ready[w]
-    int done;                                  // the consumer has finished step `done`
-};
-
-// Flags between the waves of the workgroup, in LDS.  Release = this wave's LDS operations have completed (lgkmcnt) before the flag is
-// written; acquire = LDS reads after the flag read are issued after it (LDS executes a wave's operations in order).  NOT the
-// compiler's release / acquire: those also wait for the wave's outstanding GLOBAL stores (vmcnt(0)) -- the trace rows on their way to
-// HBM, a microsecond per step that nothing in the workgroup depends on.
-__device__ __forceinline__ int pipe_flag(const int* p) {
-    const int v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    asm volatile("" ::: "memory");
-    return v;
-}
-__device__ __forceinline__ void pipe_publish(int* p, int v) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// consumer wave: fixed-point CDFs of NW weight vectors, lane l holding particles 4 l .. 4 l + 3 (consecutive: the prefix sums need no
-// transposition); numerators to registers (and, for the searched vector, to LDS), S per vector
-template <int NW>
-__device__ __forceinline__ void pipe_scan(const double (&lw)[NW][4], int n, double (&num)[NW][4], double (&S)[NW]) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) {
-        double m = __builtin_fmax(__builtin_fmax(lw[w][0], lw[w][1]), __builtin_fmax(lw[w][2], lw[w][3]));
-        m = wave_max(m);
-        const double kref = pgas_seg_ref(m);
-        double arg[4];
-        uint64_t qv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) arg[j] = pgas_seg_arg(lw[w][j], kref);
-        dev_exp_q51_n<4>(arg, qv);
-        uint64_t loc[4], run = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            run += qv[j];
-            loc[j] = run;
-        }
-        const uint64_t incl = wave_incl_scan_u64(run);
-        const uint64_t base = incl - run;
-        const uint64_t tot = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(incl >> 32), 63) << 32) |
-                             (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)incl, 63);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) num[w][j] = (4 * lane + j < n) ? pgas_u64_to_double(base + loc[j]) * PGAS_FIX_INV : __builtin_inf();
-        S[w] = pgas_u64_to_double(tot) * PGAS_FIX_INV;
-    }
-}
-
-template <int NX, int D, int JIN, int J0T>
-__global__ __launch_bounds__(320) void k_sweep_pipe(DevModel md, const TransParams* __restrict__ tpp, const double* __restrict__ G_arg,
-                                                    const SweepParams* __restrict__ swp, const double* __restrict__ u_res,
-                                                    const double* __restrict__ u_anc, const double* __restrict__ m0L0,
-                                                    const double* __restrict__ ref, double* __restrict__ x_trace,
-                                                    int32_t* __restrict__ anc_trace, double* __restrict__ logw_last,
-                                                    double* __restrict__ logw_trace /* (T, N) or NULL */, UpperHdr* __restrict__ hdr,
-                                                    double* __restrict__ traj, const double* __restrict__ znoise /* (T, N, 2): k_small_noise */) {
-    __shared__ PipeSmem sm;
-    extern __shared__ __attribute__((aligned(16))) double pg_g_lds_pipe[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int N = md.N, T = md.T;
-    const size_t row = (size_t)N * NX;
-    {
-        int gtot = NX;
-#pragma unroll
-        for (int d = 0; d < D; ++d) gtot *= (d == D - 1 && D > 1) ? JIN : md.J[d];
-        for (int i = tid; i < gtot; i += 320) pg_g_lds_pipe[i] = G_arg[i];
-        if (tid < 4) sm.ready[tid] = 0;
-        if (tid == 4) sm.done = 0;
-        lds_barrier();   // the only workgroup barrier of the kernel
-    }
-    const uint64_t seed = ld_const(&swp->seed);
-    if (wave < 4) {
-        // ================= producers: particle i = tid through every time step (src/PGAS.py:45-77,130-134)
-        TransParams tp;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            tp.LS[q] = ld_const(&tpp->LS[q]);
-            tp.LSinv[q] = ld_const(&tpp->LSinv[q]);
-        }
-        tp.cS = ld_const(&tpp->cS);
-        tp.G = G_arg;
-        const int i = tid;
-        double x[1][NX];
-        {
-            double z[2];
-            pgas_rng_normals(seed, PGAS_STREAM_INIT, 0u, (uint64_t)(i < N ? i : N - 1), NX, z);
-#pragma unroll
-            for (int k = 0; k < NX; ++k) {
-                double v = m0L0[k];
-#pragma unroll
-                for (int l = 0; l <= k; ++l) v = PGAS_FMA(m0L0[NX + k * NX + l], z[l], v);
-                x[0][k] = (i == N - 1) ? ref[k] : v;
-                if (i < N) x_trace[(size_t)i * NX + k] = x[0][k];
-            }
-        }
-        // y_t, ref_t and the particle's noise are fetched one step ahead
-        double yn[PGAS_MAX_NY], rn[NX];
-        double2 zn = make_double2(0.0, 0.0);
-        auto fetch = [&](int t) {
-#pragma unroll
-            for (int k = 0; k < PGAS_MAX_NY; ++k) yn[k] = k < md.ny ? md.y[(size_t)t * md.ny + k] : 0.0;
-#pragma unroll
-            for (int k = 0; k < NX; ++k) rn[k] = ref[(size_t)t * NX + k];
-            zn = reinterpret_cast<const double2*>(znoise)[(size_t)t * N + (i < N ? i : N - 1)];
-        };
-        if (T > 1) fetch(1);
-        for (int t = 1; t < T; ++t) {
-            const double* __restrict__ ut = md.u + (size_t)t * md.nu;
-            double yt[PGAS_MAX_NY], rf[NX];
-#pragma unroll
-            for (int k = 0; k < PGAS_MAX_NY; ++k) yt[k] = yn[k];
-#pragma unroll
-            for (int k = 0; k < NX; ++k) rf[k] = rn[k];
-            const double z[2] = {zn.x, zn.y};
-            fetch(t + 1 < T ? t + 1 : t);
-            double xt[NX], la1, h1, ln1;
-            small_particle_step<NX, D, JIN, J0T>(md, tp, pg_g_lds_pipe, ut, yt, rf, md.p0 + i == md.Ng - 1, x, z, xt, la1, h1, ln1);
-            while (pipe_flag(&sm.done) < t - PG_PIPE_RING) __builtin_amdgcn_s_sleep(1);   // the ring slot of step t is free again
-            double (&slot)[3][PG_PIPE_N] = sm.ring[t & (PG_PIPE_RING - 1)];
-            slot[0][i] = la1;
-            slot[1][i] = h1;
-            slot[2][i] = ln1;
-            if (i < N) {
-#pragma unroll
-                for (int k = 0; k < NX; ++k) {
-                    x[0][k] = xt[k];
-                    st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xt[k]);
-                }
-            }
-            pipe_publish(&sm.ready[wave], t);   // release: the slot's values are in LDS before the flag is
-        }
-        __threadfence();                       // the state trace is in memory before the consumer chases ancestors through it
-        pipe_publish(&sm.ready[wave], T);
-        return;
-    }
-    // ================= consumer: the weight recursion (src/PGAS.py:90-127,137-147), particles 4 lane .. 4 lane + 3
-    const bool pow2 = (N & (N - 1)) == 0;
-    const double invN = 1.0 / (double)N;
-    double logw[4] = {0.0, 0.0, 0.0, 0.0};
-    if (logw_trace != nullptr) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (4 * lane + j < N) logw_trace[4 * lane + j] = 0.0;
-    }
-    double u1n = T > 1 ? u_res[1] : 0.0, u2n = T > 1 ? u_anc[1] : 0.0;
-    for (int t = 1; t < T; ++t) {
-        const double u1 = u1n, u2 = u2n;
-        u1n = u_res[t + 1 < T ? t + 1 : t];   // next step's uniforms, requested early
-        u2n = u_anc[t + 1 < T ? t + 1 : t];
-        // the data-independent half of the thresholds first (a division when N is no power of two)
-        double U[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) U[j] = slot_U(u1, 4 * lane + j, N, invN, pow2);
-        for (;;) {
-            const int r = lane < 4 ? pipe_flag(&sm.ready[lane]) : T;
-            if (__ballot(r < t) == 0ull) break;
-            __builtin_amdgcn_s_sleep(1);
-        }
-        const double (&slot)[3][PG_PIPE_N] = sm.ring[t & (PG_PIPE_RING - 1)];
-        double lw[2][4], ln[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = 4 * lane + j;
-            const double l1 = slot[0][i] + logw[j];   // src/PGAS.py:101-102
-            lw[0][j] = i < N ? l1 : -__builtin_inf();
-            lw[1][j] = i < N ? l1 + slot[1][i] : -__builtin_inf();   // :117-118
-            ln[j] = slot[2][i];
-        }
-        double num[2][4], S[2];
-        pipe_scan<2>(lw, N, num, S);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sm.num[0][4 * lane + j] = num[0][j];
-        const bool valid1 = (S[0] > 0.0) && (S[0] < __builtin_inf()), valid2 = (S[1] > 0.0) && (S[1] < __builtin_inf());
-        // ancestor of the conditioned particle (src/PGAS.py:121-127): a count against this lane's own numerators
-        const double tau2 = u2 * S[1];
-        int c2 = 0;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) c2 += (num[1][j] < tau2) ? 1 : 0;
-        c2 = wave_sum_i(c2);
-        const int ref_idx = valid2 ? (c2 > N - 1 ? N - 1 : c2) : N - 1;
-        // systematic resampling (src/Filtering.py:28-35): four slots per lane, four independent lower-bound chains
-        int a[4];
-        double tau[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) tau[j] = U[j] * S[0];
-        {
-            int p[4] = {0, 0, 0, 0};
-#pragma unroll
-            for (int step = PG_PIPE_N / 2; step >= 1; step >>= 1) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const double v = sm.num[0][p[j] + step - 1];
-                    p[j] = (v < tau[j]) ? p[j] + step : p[j];
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int i = 4 * lane + j;
-                const int pj = (sm.num[0][p[j]] < tau[j]) ? p[j] + 1 : p[j];
-                a[j] = valid1 ? (pj > N - 1 ? N - 1 : pj) : (i < N ? i : N - 1);
-                if (i == N - 1) a[j] = ref_idx;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int i = 4 * lane + j;
-            const double lav = slot[0][a[j]];
-            if (i < N) {
-                anc_trace[(size_t)(t - 1) * N + i] = (int32_t)a[j];   // plain store: the back-trace of this very launch reads it (L2)
-                logw[j] = ln[j] - lav;   // src/PGAS.py:137-147
-                if (logw_trace != nullptr) logw_trace[(size_t)t * N + i] = logw[j];
-            }
-        }
-        pipe_publish(&sm.done, t);   // the slot of step t may be overwritten (the reads above are complete: release)
-    }
-    // ---- final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
-    double lwf[1][4], numf[1][4], Sf[1];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = 4 * lane + j;
-        lwf[0][j] = i < N ? logw[j] : -__builtin_inf();
-        if (i < N) logw_last[i] = logw[j];
-    }
-    pipe_scan<1>(lwf, N, numf, Sf);
-    const double tauf = ld_const(&swp->u_final) * Sf[0];
-    int cf = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) cf += (numf[0][j] < tauf) ? 1 : 0;
-    cf = wave_sum_i(cf);
-    const bool validf = (Sf[0] > 0.0) && (Sf[0] < __builtin_inf());
-    const int fidx = validf ? (cf > N - 1 ? N - 1 : cf) : N - 1;
-    for (;;) {   // every producer has written and fenced its part of the state trace
-        const int r = lane < 4 ? pipe_flag(&sm.ready[lane]) : T;
-        if (__ballot(r < T) == 0ull) break;
-        __builtin_amdgcn_s_sleep(1);
-    }
-    __threadfence();   // this wave's own ancestor stores
-    if (lane == 0) {
-        hdr->final_idx = fidx;
-        int b = fidx;
-#ifdef PG_SMALL_NO_BT
-        if (T > 0) return;
-#endif
-        for (int i = T - 1; i >= 0; --i) {
-#pragma unroll
-            for (int k = 0; k < NX; ++k) traj[(size_t)i * NX + k] = __hip_atomic_load(&x_trace[(size_t)i * row + (size_t)b * NX + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (i > 0) b = __hip_atomic_load(&anc_trace[(size_t)(i - 1) * N + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}

@@ -96,9 +96,7 @@ def test_basis_init_step_bit_exact(name, N):
     # the general multi-launch path at the same sizes
     ("smo", 200, {14: 0}), ("smo", 1024, {14: 0}), ("toy", 300, {14: 0}), ("emps", 500, {14: 0}), ("veh", 640, {14: 0}), ("smo", 777, {14: 0, 7: 1}), ("toy", 1, {14: 0}),
     ("smo", 256, {}), ("smo", 257, {}), ("toy", 1024, {}), ("emps27", 1000, {}), ("smo", 513, {13: 1, 14: 0}),
-    # 14: 2 = the lock-step single-workgroup kernel where the default is the in-workgroup pipeline (N <= 256)
-    ("smo", 200, {14: 2}), ("toy", 1, {14: 2}), ("emps", 250, {14: 2}), ("emps", 250, {}), ("veh", 130, {}), ("veh27", 256, {}), ("toy", 255, {}), ("smo", 2, {}), ("smo", 63, {}),
-    ("smo", 1024, {}), ("smo", 777, {}), ("toy", 300, {}), ("toy", 1, {}), ("emps", 500, {}), ("veh", 640, {}), ("veh27", 1000, {}), ("smo", 777, {7: 1}),
+    ("emps", 250, {}), ("veh", 130, {}), ("veh27", 256, {}), ("toy", 255, {}), ("smo", 2, {}), ("smo", 63, {}),
 ])
 def test_sweep_bit_exact(name, N, opts):
     pb, A, S, cm, csmc = _setup(name, N)
