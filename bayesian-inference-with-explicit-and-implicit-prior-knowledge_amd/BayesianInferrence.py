@@ -62,14 +62,15 @@ def prior_mniw_Predictive(mean, col_cov, row_scale, df, basis):
 def prior_mniw_drawPred(key, mean, col_scale, row_scale, df):
     """One draw from the matrix-t predictive [BI:92-108]: mean + chol(row) t chol(col)^T with t ~ Student-t(df), one variate per
     row dimension.  `key` is a pgas_amd.random key (own Philox streams: the reference's jax.random.t stream is not reproducible
-    here); t = z / sqrt(chi2(df) / df)."""
+    here).  The variates are the library's (pgas_m_rng_student_t_host: z sqrt(a / Gamma(a)), a = df / 2, stream 32 of the key) -- the
+    arithmetic the device kernels use, so a host draw and a device draw from the same counters are the same number."""
     from . import random as prng
+    from ._lib import student_t_host
 
     Lc = np.linalg.cholesky(np.atleast_2d(np.asarray(col_scale, dtype=np.float64)))
     Lr = np.linalg.cholesky(np.atleast_2d(np.asarray(row_scale, dtype=np.float64)))
     n = Lr.shape[0]
-    kz, kc = prng.split(prng.as_key(key), 2)
-    t = prng.normal(kz, (n,)) / np.sqrt(prng.chisquare(kc, np.full(n, float(df))) / float(df))
+    t = student_t_host(prng.as_key(key), prng.STREAM_INTVAR, 0, np.full(n, float(df)))
     return np.asarray(mean, dtype=np.float64) + np.squeeze(np.einsum("ij,j,jk->ik", Lr, t, Lc.T))
 
 

@@ -40,7 +40,7 @@ EXPORTS = [
     "pgas_trace_layout", "pgas_trace_row",
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_layout", "pgas_shard_block", "pgas_shard_set_peer_block", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
     "pgas_hip_runtime_version", "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
-    "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_chi2", "pgas_m_set_time_source", "pgas_m_rng_uniform_dev", "pgas_systematic_resample_dev", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
+    "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_student_t_host", "pgas_m_rng_chi2", "pgas_m_set_time_source", "pgas_m_rng_uniform_dev", "pgas_systematic_resample_dev", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)   # pgas_allgather_fn (include/pgas_hip.h)
@@ -152,6 +152,8 @@ def load():
     L.pgas_m_rng_normal.argtypes = [vp, u64, u32, u32, i64, i64, i32, vp, vp]
     L.pgas_m_rng_student_t.restype = C.c_int
     L.pgas_m_rng_student_t.argtypes = [vp, u64, u32, u32, i64, i64, vp, vp, vp]
+    L.pgas_m_rng_student_t_host.restype = C.c_int
+    L.pgas_m_rng_student_t_host.argtypes = [u64, u32, u32, i64, i64, _dp, _dp]
     L.pgas_m_set_time_source.restype = C.c_int
     L.pgas_m_set_time_source.argtypes = [vp, vp]
     L.pgas_m_rng_uniform_dev.restype = C.c_int
@@ -200,6 +202,17 @@ def detmath_eval(which, x=None, y=None, words=None, device=None):
         raise PgasError(f"pgas_detmath_eval failed ({rc})")
     torch.cuda.synchronize(dev)
     return o0.cpu().numpy(), o1.cpu().numpy(), ow.cpu().numpy().view(np.uint32).reshape(n, 4)
+
+
+def student_t_host(seed, stream, t, nu, p0=0):
+    """Student-t variates of counters (particle p0 .. p0 + len(nu) - 1, t, stream) computed on the HOST by the library's own arithmetic:
+    bit-identical to what k_rng_student_t produces on the device (pgas_m_rng_student_t_host)."""
+    nu = np.ascontiguousarray(np.atleast_1d(nu), dtype=np.float64)
+    out = np.empty_like(nu)
+    rc = load().pgas_m_rng_student_t_host(int(seed), int(stream), int(t), int(p0), nu.size, _hp(nu), _hp(out))
+    if rc != 0:
+        raise PgasError(f"pgas_m_rng_student_t_host failed ({rc})")
+    return out
 
 
 class _DevView:

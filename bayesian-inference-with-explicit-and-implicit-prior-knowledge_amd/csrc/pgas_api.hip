@@ -1742,6 +1742,14 @@ int pgas_m_rng_student_t(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t
     return PGAS_OK;
 }
 
+/* The same variates on the HOST (no context, no device): the library's own arithmetic (include/pgas_canon.h) compiled for the CPU, so
+ * that host-side helpers (pgas_amd.prior_mniw_drawPred, BI:92-108) draw from the SAME streams as the kernels, bit for bit. */
+int pgas_m_rng_student_t_host(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu_host, double* out_host) {
+    if (!nu_host || !out_host || n < 0) return PGAS_E_ARG;
+    for (int64_t p = 0; p < n; ++p) out_host[p] = pgas_rng_student_t(seed, stream, t, (uint64_t)(p0 + p), nu_host[p]);
+    return PGAS_OK;
+}
+
 int pgas_m_rng_chi2(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu, double* out, void* sh) {
     if (!c) return PGAS_E_ARG;
     if (!out || !nu || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_rng_chi2: bad argument");

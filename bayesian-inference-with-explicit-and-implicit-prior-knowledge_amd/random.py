@@ -16,6 +16,10 @@ _MASK = 0xFFFFFFFF
 STREAM_SPLIT = 16
 STREAM_PARAM_NORMAL = 17
 STREAM_PARAM_UNIFORM = 18
+STREAM_INTVAR = 32   # PGAS_STREAM_M_INTVAR (include/pgas_canon.h): Student-t variates of prior_mniw_drawPred
+
+# Normal, chi^2 and Student-t variates are NOT generated in this module: they come from the library (device kernels k_rng_normal /
+# k_rng_chi2 / k_rng_student_t, or pgas_m_rng_student_t_host for host-side helpers), one arithmetic for one key type.
 
 
 def philox4x32_10(ctr, key):
@@ -63,44 +67,4 @@ def uniform(k, n: int, stream: int = STREAM_PARAM_UNIFORM) -> np.ndarray:
         out[i] = _u52(w[0], w[1])
         if i + 1 < n:
             out[i + 1] = _u52(w[2], w[3])
-    return out
-
-
-def normal(k, shape, stream: int = STREAM_PARAM_NORMAL) -> np.ndarray:
-    """Standard normals (Box-Muller on Philox uniforms); used for parameter draws only."""
-    k = as_key(k)
-    n = int(np.prod(shape)) if np.ndim(shape) else int(shape)
-    out = np.empty(n + (n & 1))
-    for i in range(0, n, 2):
-        w = philox4x32_10((i // 2, 0, 0, stream), (k & _MASK, k >> 32))
-        ua, ub = _u52(w[0], w[1]), _u52(w[2], w[3])
-        rad = np.sqrt(-2.0 * np.log(ua))
-        out[i], out[i + 1] = rad * np.cos(2 * np.pi * ub), rad * np.sin(2 * np.pi * ub)
-    return out[:n].reshape(shape)
-
-
-def chisquare(k, df) -> np.ndarray:
-    """chi^2(df_i) draws via Marsaglia-Tsang gamma sampling on Philox streams (df_i > 0)."""
-    df = np.atleast_1d(np.asarray(df, dtype=np.float64))
-    out = np.empty_like(df)
-    subkeys = split(k, len(df))
-    for i, (nu, sk) in enumerate(zip(df, subkeys)):
-        a = nu / 2.0
-        boost = 1.0
-        if a < 1.0:  # Gamma(a) = Gamma(a+1) * U^(1/a)
-            boost = uniform(sk, 1, stream=STREAM_PARAM_UNIFORM + 1)[0] ** (1.0 / a)
-            a += 1.0
-        d = a - 1.0 / 3.0
-        c = 1.0 / np.sqrt(9.0 * d)
-        zs = normal(sk, 64)
-        us = uniform(sk, 64)
-        val = None
-        for z, u in zip(zs, us):
-            v = (1.0 + c * z) ** 3
-            if v > 0 and np.log(u) < 0.5 * z * z + d - d * v + d * np.log(v):
-                val = d * v
-                break
-        if val is None:  # 64 consecutive rejections has probability < 1e-80
-            raise RuntimeError("gamma sampler failed to accept")
-        out[i] = 2.0 * val * boost
     return out

@@ -37,6 +37,9 @@ int pgas_m_rng_uniform_dev(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32
 
 int pgas_m_rng_student_t(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu_dev,
                          double* out_dev, void* stream_handle);
+/* The same Student-t variates computed on the HOST by the library's own arithmetic (no context, no device; bit-identical to the
+ * kernel's): for host-side helpers such as prior_mniw_drawPred (BI:92-108), so that one key never means two samplers. */
+int pgas_m_rng_student_t_host(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu_host, double* out_host);
 
 /* chi^2(nu_p) variates, out[p] = 2 Gamma(nu_p / 2) on the counters of particle p0 + p (pgas_rng_gamma, include/pgas_canon.h): the
  * diagonal of the Bartlett factor in PGAS.sample_params (reference src/PGAS.py:323-327, jax.random.chisquare there). */

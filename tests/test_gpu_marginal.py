@@ -30,6 +30,8 @@ def test_rng_kernels_bit_exact():
     nu = np.concatenate([np.full(1000, 1.0), np.full(1000, 3.0), np.linspace(2.0, 2000.0, 3000)])
     t = ops.student_t(SEED, 32, 4, torch.as_tensor(nu)).cpu().numpy()
     assert np.array_equal(t, canon.student_t(SEED, 32, 4, 0, nu))
+    from pgas_amd._lib import student_t_host
+    assert np.array_equal(t, student_t_host(SEED, 32, 4, nu)), "host-side helper draws (prior_mniw_drawPred) and device draws are one sampler"
     assert ops.uniform(SEED, 18, 7) == canon.uniform(SEED, 18, 7)
 
 

@@ -54,16 +54,21 @@ def test_mniw_host_functions_match_restatement():
     assert st[0].shape == (3, 2) and st[1].shape == (3, 3) and st[2].shape == (2, 2) and st[3] == 1
 
 
-def test_keys_and_param_draws():
+def test_keys_and_host_student_t():
+    """Key handling, and the one host-side sampler left in the package: Student-t variates computed by the library's own arithmetic on
+    the CPU (pgas_m_rng_student_t_host) -- identical to the canonical C oracle's, which is what the device kernel reproduces
+    (tests/test_gpu_marginal.py) -- with the right distribution."""
+    from oracle import canon
+    from pgas_amd._lib import student_t_host
+
     k = prng.key(12345678)
     a, b = prng.split(k, 2)
     assert a != b and prng.split(k, 2) == [a, b]
-    z = prng.normal(a, (200, 50))
-    assert abs(z.mean()) < 0.03 and abs(z.std() - 1) < 0.03
-    c = prng.chisquare(b, np.array([2001.0, 2000.0, 0.7]))
-    assert 1800 < c[0] < 2200 and 1800 < c[1] < 2200 and c[2] > 0
-    draws = np.array([prng.chisquare(s, [5.0])[0] for s in prng.split(k, 400)])
-    assert abs(draws.mean() - 5.0) < 0.5
+    nu = np.full(4000, 5.0)
+    t = student_t_host(a, prng.STREAM_INTVAR, 3, nu)
+    assert np.array_equal(t, canon.student_t(a, prng.STREAM_INTVAR, 3, 0, nu))
+    assert abs(t.mean()) < 0.1 and abs(t.var() / (5.0 / 3.0) - 1) < 0.25   # Var t_5 = 5/3
+    assert not hasattr(prng, "normal") and not hasattr(prng, "chisquare"), "normal / chi^2 variates come from the library, not from a second host sampler"
 
 
 def test_experiment_definitions():
