@@ -561,6 +561,20 @@ def main():
             out["cpu_baseline"] = cpu_baseline(pb, Ah, Sh, N, seed, args.cpu_steps)
             if args.workload == "smo":
                 out["cpu_baseline"]["config1"] = numpy_baseline_config1(pb, Ah, Sh, seed)
+                # the engine at the same size (N = 200: the whole sweep is one launch of one workgroup, k_sweep_small), beside the CPU figures
+                small = pgas_amd.condSequentialMonteCarlo(200, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn,
+                                                          pb.basis_fcn, device=f"cuda:{local_rank}")
+                small(seed, ref, A, S)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for k in range(5):
+                    small(seed + 1 + k, ref, A, S)
+                torch.cuda.synchronize()
+                ms = 1e3 * (time.perf_counter() - t1) / 5
+                out["cpu_baseline"]["config1"]["engine"] = {"value": 200 * (T - 1) / (ms * 1e-3), "unit": "particle-steps/s", "ms_per_sweep": ms,
+                                                            "kernel": "k_sweep_small" if small.engine.launch_info()["small"] else "general path",
+                                                            "note": "this repository's engine on the same N = 200, T = 2000 sweep (1 x MI355X, mean of 5 sweeps)"}
+                small.engine.close()
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
