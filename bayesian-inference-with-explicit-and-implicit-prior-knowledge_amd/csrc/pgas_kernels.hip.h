@@ -730,8 +730,15 @@ __device__ __forceinline__ void dev_exp_q51_n(const double (&x)[NB], uint64_t (&
     }
 }
 
+// Transposition array of the segment scans: thread t WRITES the numerators of particles r * 256 + t (r = 0..3) and READS those of
+// particles 4 t .. 4 t + 3 for the prefix sums.  Element i lives at plane (i & 3), slot (i >> 2), planes PG_QPLANE = 256 + 8 words
+// apart: the reads (lane stride 8 bytes inside a plane) and the writes (planes 16 banks apart, 8 consecutive slots per plane in each
+// half-wave) are both free of LDS bank conflicts.  Laid out linearly, the four 8-byte reads of a lane sat 32 bytes from its
+// neighbour's: four lanes per bank (most of the 38 % conflict cycles round 2 measured in k_step, profiles/r02_pmc_sq_lds.txt).
+#define PG_QPLANE (PG_BLK + 8)
+__device__ __forceinline__ int q_slot(int i) { return (i & 3) * PG_QPLANE + (i >> 2); }
 struct ScanSmem {
-    uint64_t q[2][PGAS_SEG];
+    uint64_t q[2][4 * PG_QPLANE];
     double red[2][PG_BLK / 64];
     uint64_t wtot[2][PG_BLK / 64];
 };
@@ -770,7 +777,7 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
             dev_exp_q51_n<PG_PPT>(arg, qv);
 #pragma unroll
             for (int r = 0; r < PG_PPT; ++r) {
-                if (w == 0 || STORE_B) sm.q[w][r * PG_BLK + tid] = qv[r];  // strided -> contiguous particle order for the prefix
+                if (w == 0 || STORE_B) sm.q[w][q_slot(r * PG_BLK + tid)] = qv[r];  // strided -> contiguous particle order for the prefix
                 else qsum_b += qv[r];                                      // only the segment total is wanted: any order will do
             }
         }
@@ -783,7 +790,7 @@ __device__ __forceinline__ void segment_scan(ScanSmem& sm, const double (&lw)[NW
         if (w == 0 || STORE_B) {
 #pragma unroll
             for (int j = 0; j < PG_PPT; ++j) {
-                run += sm.q[w][PG_PPT * tid + j];
+                run += sm.q[w][j * PG_QPLANE + tid];   // = q_slot(4 tid + j)
                 loc[w][j] = run;
             }
         } else {

@@ -505,27 +505,26 @@ __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOC
                 }
             const double g_carry = sm.cand_cy[k0w];
             // global loads first, then the barrier that frees the table / the previous window
-            ulonglong2 c01[PG_FSTAGE], c23[PG_FSTAGE];
+            // thread -> elements j * 256 + tid of every staged segment: 8-byte accesses with consecutive lanes on consecutive words, for the
+            // global loads (512 contiguous bytes per wave instruction) and for the LDS stores (no bank conflicts; 32-byte-strided
+            // 16-byte stores of four consecutive elements per lane put two lanes on every bank)
+            uint64_t cq[PG_FSTAGE][PG_PPT];
 #pragma unroll
             for (int g = 0; g < PG_FSTAGE; ++g)
                 if (g < ng) {
-                    const ulonglong2* src = reinterpret_cast<const ulonglong2*>(c1_segment(sb, pr, sb_idx[g])) + 2 * tid;
-                    c01[g] = src[0];
-                    c23[g] = src[1];
+                    const uint64_t* src = c1_segment(sb, pr, sb_idx[g]);
+#pragma unroll
+                    for (int j = 0; j < PG_PPT; ++j) cq[g][j] = src[j * PG_BLK + tid];
                 }
             __syncthreads();
 #pragma unroll
             for (int g = 0; g < PG_FSTAGE; ++g) {
-                double4 v = make_double4(__builtin_inf(), __builtin_inf(), __builtin_inf(), __builtin_inf());
-                if (g < ng) {
-                    const int n = seg_count(N, sb_idx[g]);
-                    const int k0 = PG_PPT * tid;
-                    if (k0 + 0 < n) v.x = num_of(c01[g].x, sp[g]);
-                    if (k0 + 1 < n) v.y = num_of(c01[g].y, sp[g]);
-                    if (k0 + 2 < n) v.z = num_of(c23[g].x, sp[g]);
-                    if (k0 + 3 < n) v.w = num_of(c23[g].y, sp[g]);
+                const int n = g < ng ? seg_count(N, sb_idx[g]) : 0;
+#pragma unroll
+                for (int j = 0; j < PG_PPT; ++j) {
+                    const int k = j * PG_BLK + tid;
+                    sm.u.num[g][k] = k < n ? num_of(cq[g][j], sp[g]) : __builtin_inf();
                 }
-                reinterpret_cast<double4*>(sm.u.num[g])[tid] = v;
             }
             __syncthreads();
             PG_STAMP(3);

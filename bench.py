@@ -353,7 +353,7 @@ def main():
     ref = torch.as_tensor(pb.X_true, device=pg.cSMC.engine.device)
     # (A, S) from one sample_params on the initial reference trajectory
     A, S = pg.sample_params(pgas_amd.random.key(seed), ref)
-    stride = int(os.environ.get("PGAS_PROF_STRIDE", "1"))       # time every stride-th launch of the profiled sweep(s)
+    stride = int(os.environ.get("PGAS_PROF_STRIDE", "4"))       # time every stride-th launch of the profiled sweep(s)
     prof_all = os.environ.get("PGAS_PROF_ALL", "0") == "1"      # profile every timed sweep instead of the last one only
 
     def barrier():
