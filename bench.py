@@ -516,7 +516,7 @@ def main():
             oth["achieved_GBs"] = per_launch * oth["steps_per_launch"] / (oth["avg_launch_us"] * 1e-6) / 1e9
             sweep_GBs = ALG_BYTES_PER_PARTICLE_STEP * units / dt / world / 1e9   # per GPU
             traffic, traffic_src = None, None
-            for tf in (("traffic_r02.json", "traffic_r01.json") if args.workload == "smo" else ()):   # the stored counters are of the smo workload
+            for tf in (("traffic_r03.json", "traffic_r02.json", "traffic_r01.json") if args.workload == "smo" else ()):   # the stored counters are of the smo workload
                 tp = os.path.join(ROOT, "profiles", tf)
                 if os.path.exists(tp):
                     tj = json.load(open(tp))
@@ -532,7 +532,7 @@ def main():
                             # every VALU instruction of a wave64 occupies its SIMD for 4 cycles (16 lanes per clock); 1024 SIMDs at ~2.1 GHz under this load
                             out["valu"]["summary"] = {"lane_instr_per_particle_step": tot, "issue_bound_us_per_step": tot * N / 64 * 4 / 1024 / 2.1e3,
                                                       "measured_us_per_step": 1e6 * dt / args.steps / (T - 1),
-                                                      "note": "stored PMC counts (SQ_INSTS_VALU x 64 / N per kernel, profiles/traffic_r02.json), not taken in this run"}
+                                                      "note": f"stored PMC counts (SQ_INSTS_VALU x 64 / N per kernel, profiles/{tf}), not taken in this run"}
                         break
             # SURVEY 8(d), secondary figure: algorithmic flops per particle-step = 2 M nx (Phi A^T) + M (D - 1) (products) against the
             # fp64 vector peak -- the bound that matters for the M = 729 configurations
@@ -553,8 +553,9 @@ def main():
                 "sweep_note": "sweep_* = 52 B x N x (T-1) / wall of the whole sweep per GPU: both kernels, launch gaps, final draw and back-trace included",
                 "hbm_copy_GBs": hbm_copy_rate(torch, eng.device),   # measured attainable rate of a 1 GiB device copy, outside the timed region
                 "second_kernel": oth,
-                "note": "the two kernels run concurrently on two streams; k_propagate is fp64-VALU-bound (82 % VALU-busy alone), k_step is a chain of dependent "
-                        "global round trips (70 % of its wave cycles are waits): DESIGN.md section 5, profiles/r02_pmc_sq_*.txt -- the HBM fraction says little about either",
+                "note": "the two kernels run concurrently on two streams and share the vector ALUs; together they issue ~850 fp64-rate vector instructions per "
+                        "particle-step, which bounds a step at ~26 us against 6.8 us of HBM time: DESIGN.md section 5, profiles/r03_pmc_sq_*.txt -- the HBM fraction "
+                        "says little about either kernel",
             }
         if args.cpu_steps > 0 and world == 1:
             Ah, Sh = A.cpu().numpy(), S.cpu().numpy()
