@@ -96,6 +96,8 @@ typedef void (*aux_fn)(DevModel, const TransParams*, int, const double*, double*
 typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, Peers, int32_t*, double*);
 typedef void (*init_fn)(DevModel, uint64_t, const SweepParams*, const double*, const double*, double*);
 typedef void (*basis_fn)(DevModel, const int32_t*, const double*, int64_t, int, double*);
+typedef void (*duo_fn)(DevModel, const TransParams*, const double*, const SweepParams*, const double*, const double*, const double*, const double*, double*, int32_t*,
+                       double*, double*, UpperHdr*, double*, const double*, DuoShared*);
 typedef void (*small_fn)(DevModel, const TransParams*, const double*, const SweepParams*, const double*, const double*, const double*, const double*, double*, int32_t*,
                          double*, double*, UpperHdr*, double*, const double*);
 
@@ -107,13 +109,15 @@ struct Variant {
     int P, W;   // particles per basis pass, waves per SIMD the k_propagate instantiation is built for
     int PPT;    // particles per thread of k_propagate: its grid is ceil(nseg / (PPT / 4))
     small_fn small[3];   // the whole sweep in one workgroup (N <= 256, 512, 1024: one, two, four particles per thread)
+    duo_fn duo[3];       // ... on two workgroups: propagation ahead, weight recursion behind (the default)
 };
 
 template <int NX, int D, int JIN, int P, int W, int J0T = 0, int PPT = PG_PPT>
 Variant make_variant() {
     const prop_fn one = k_propagate<NX, D, JIN, P, W, J0T, PPT, true>;
     return Variant{k_front<NX, D, JIN, P>, k_propagate<NX, D, JIN, P, W, J0T, PPT>, one, k_aux<NX, D, JIN, P>, P, W, PPT,
-                   {k_sweep_small<NX, D, JIN, J0T, 1>, k_sweep_small<NX, D, JIN, J0T, 2>, k_sweep_small<NX, D, JIN, J0T, 4>}};
+                   {k_sweep_small<NX, D, JIN, J0T, 1>, k_sweep_small<NX, D, JIN, J0T, 2>, k_sweep_small<NX, D, JIN, J0T, 4>},
+                   {k_sweep_duo<NX, D, JIN, J0T, 1>, k_sweep_duo<NX, D, JIN, J0T, 2>, k_sweep_duo<NX, D, JIN, J0T, 4>}};
 }
 
 // (nx, D, padded innermost extent) -> kernel instantiation <NX, D, JIN, P particles per basis pass, W waves/SIMD>
@@ -212,6 +216,7 @@ struct pgas_ctx {
     int use_small = 1;             // PGAS_OPT_SMALL_SWEEP: contexts of at most one segment run the whole sweep in one workgroup (k_sweep_small)
     int last_small = 0;            // 1: the last pgas_sweep did
     double* d_znoise = nullptr;    // (T, N, 2) propagation noise of a single-workgroup sweep (k_small_noise)
+    DuoShared* d_duo = nullptr;    // ring and counters between the two workgroups of k_sweep_duo
     int graph_failed = 0;          // capture or instantiation failed once: stay on the eager path
     hipStream_t sG = nullptr;      // the stream captured sweeps are recorded on and replayed on (the caller's may be the legacy default
                                    // stream, which cannot be captured); ordered against the caller's stream with ev_g0 / ev_g1
@@ -471,7 +476,7 @@ void pgas_destroy(pgas_ctx* c) {
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
     if (c->ev_g1) (void)hipEventDestroy(c->ev_g1);
     if (c->sG) (void)hipStreamDestroy(c->sG);
-    hipFree(c->d_znoise);
+    hipFree(c->d_znoise); hipFree(c->d_duo);
     hipFree(c->d_tp); hipFree(c->d_sp); hipFree(c->d_ures); hipFree(c->d_uanc); hipFree(c->d_refbuf); hipFree(c->d_trajbuf);
     hipFree(c->d_G); hipFree(c->logw_last); hipFree(c->logw_trace); hipFree(c->d_bt);
     for (RowStore& r : c->rs) r.release();
@@ -1068,7 +1073,19 @@ int pgas_sweep(pgas_ctx* c, uint64_t seed, const double* ref_dev, double* traj_d
         }
         const size_t lds = (size_t)c->gtotal * sizeof(double);   // the coefficient tensor, beside 41 KB of static LDS
         if (lds > 64 * 1024) FAIL(c, PGAS_E_ARG, "k_sweep_small: coefficient tensor of %zu bytes does not fit the LDS budget", lds);
-        hipLaunchKernelGGL(c->var.small[N <= PG_BLK ? 0 : (N <= 2 * PG_BLK ? 1 : 2)], dim3(1), dim3(PG_BLK), lds, st, md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp,
+        const int nri = N <= PG_BLK ? 0 : (N <= 2 * PG_BLK ? 1 : 2);
+        if (c->use_small == 1) {   // default: two workgroups (PGAS_OPT_SMALL_SWEEP = 2: one)
+            if (!c->d_duo) HIPCHK(c, hipMalloc(&c->d_duo, sizeof(DuoShared)));
+            HIPCHK(c, hipMemsetAsync(c->d_duo, 0, 64, st));   // the two counters
+            hipLaunchKernelGGL(c->var.duo[nri], dim3(2), dim3(PG_BLK), lds, st, md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp,
+                               (const double*)c->d_ures, (const double*)c->d_uanc, (const double*)c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].blk[0],
+                               (int32_t*)c->rs[PG_RB_ANC].blk[0], c->logw_last, c->logw_trace, c->sb[T & 1].hdr, traj_dev, (const double*)c->d_znoise, c->d_duo);
+            KCHK(c, "k_sweep_duo");
+            c->last_small = 1;
+            c->last_chunk = 1;
+            return PGAS_OK;
+        }
+        hipLaunchKernelGGL(c->var.small[nri], dim3(1), dim3(PG_BLK), lds, st, md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp,
                            (const double*)c->d_ures, (const double*)c->d_uanc, (const double*)c->d_m0L0, ref_dev, (double*)c->rs[PG_RB_X].blk[0],
                            (int32_t*)c->rs[PG_RB_ANC].blk[0], c->logw_last, c->logw_trace, c->sb[T & 1].hdr, traj_dev, (const double*)c->d_znoise);
         KCHK(c, "k_sweep_small");
@@ -1202,7 +1219,8 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         return PGAS_OK;
     }
     if (option == PGAS_OPT_SMALL_SWEEP) {
-        c->use_small = value ? 1 : 0;
+        if (value < 0 || value > 2) FAIL(c, PGAS_E_ARG, "pgas_set_option: PGAS_OPT_SMALL_SWEEP takes 0, 1 or 2");
+        c->use_small = (int)value;
         return PGAS_OK;
     }
     if (option == PGAS_OPT_GRAPH) {

@@ -1099,6 +1099,7 @@ __device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW]
         if (lane == 0) sm.red[w][wave] = m;
     }
     lds_barrier();
+    uint64_t qkeep[NW] = {};
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         double m = sm.red[w][0];
@@ -1110,17 +1111,20 @@ __device__ __forceinline__ void small_scan(SmallSmem& sm, const double (&lw)[NW]
 #pragma unroll
         for (int r = 0; r < NR; ++r) arg[r] = pgas_seg_arg(lw[w][r], kref);
         dev_exp_q51_n<NR>(arg, qv);
+        if constexpr (NR == 1) qkeep[w] = qv[0];   // one particle per thread: thread order IS particle order, nothing to transpose
+        else {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) sm.q[w][r * PG_BLK + tid] = qv[r];
+            for (int r = 0; r < NR; ++r) sm.q[w][r * PG_BLK + tid] = qv[r];
+        }
     }
-    lds_barrier();
+    if constexpr (NR > 1) lds_barrier();
     uint64_t loc[NW][NR], incl[NW];
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
         uint64_t run = 0;
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
-            run += sm.q[w][NR * tid + j];
+            run += NR == 1 ? qkeep[w] : sm.q[w][NR * tid + j];
             loc[w][j] = run;
         }
         incl[w] = wave_incl_scan_u64(run);
@@ -1283,12 +1287,22 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
             }
             sm.la[i] = la1;
         }
+#ifdef PG_STAMPS
+#define PG_SSTAMP(k) do { if (tid == 0 && (t == 100 || t == 101)) g_stamps[(t - 100) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+        PG_SSTAMP(0);
+        lds_barrier();   // diagnostic build only: a phase boundary after the propagation
+        PG_SSTAMP(1);
+#else
+#define PG_SSTAMP(k) do { } while (0)
+#endif
         double S[2];
         small_scan<2, NR>(sm, lw, N, S);   // ends with a barrier: sm.num and sm.la are visible
+        PG_SSTAMP(2);
         // ---- systematic resampling (src/Filtering.py:28-35) and the ancestor of the conditioned particle (src/PGAS.py:121-127)
         const bool valid1 = (S[0] > 0.0) && (S[0] < __builtin_inf()), valid2 = (S[1] > 0.0) && (S[1] < __builtin_inf());
         const int cnt2 = small_count<NR>(sm, sm.num[1], u2 * S[1]);
         const int ref_idx = valid2 ? (cnt2 > N - 1 ? N - 1 : cnt2) : N - 1;
+        PG_SSTAMP(3);
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int i = r * PG_BLK + tid;
@@ -1305,6 +1319,7 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
             }
         }
         lds_barrier();   // sm.la / sm.num are rewritten by the next step
+        PG_SSTAMP(4);
     }
 
     // ---- final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
@@ -1333,6 +1348,291 @@ __global__ __launch_bounds__(PG_BLK) void k_sweep_small(DevModel md, const Trans
 #pragma unroll
             for (int k = 0; k < NX; ++k) traj[(size_t)i * NX + k] = __hip_atomic_load(&x_trace[(size_t)i * row + (size_t)b * NX + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (i > 0) b = __hip_atomic_load(&anc_trace[(size_t)(i - 1) * N + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sweep_duo: the small sweep (N <= 1024) on TWO workgroups -- the structure of the large sweep in
+// miniature.  Quirk Q1: x_t[i] depends on x_{t-1}[i] only, so workgroup 0 runs the propagation of every step ahead and leaves
+// (log p(y_t|aux_t), log N(ref_t; aux_t, S), log p(y_t|x_t)) of every particle in a ring in device memory; workgroup 1 runs the
+// weight recursion (both softmax scans, resampling search, ancestor draw, weight update) one ring slot behind, then the final index
+// and the back-trace.  In k_sweep_small the two halves add up inside every step (3 100 + 4 200 of 7 300 cycles at N = 200); here they
+// overlap.  Inside ONE workgroup they cannot: a workgroup barrier is for all of its waves, and the recursion needs seven per step.
+// The two meet through two counters in device memory (agent-scope release / acquire); the propagation never waits for the
+// recursion except for ring space, so with both workgroups resident -- a grid of two -- the pipeline cannot deadlock.
+// ------------------------------------------------------------------------------------------
+#define PG_DUO_RING 16
+struct DuoShared {   // device memory, one per context
+    int ready;       // propagation has delivered steps <= ready (T when it has also fenced its trace stores)
+    int done;        // the recursion has consumed steps <= done
+    int pad[14];
+    double ring[PG_DUO_RING][3][PGAS_SEG];
+};
+__device__ __forceinline__ int duo_poll(const int* p) { return __hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Lineage checkpoints of the recursion workgroup (N <= 1024: indices fit 16 bits).  The back-trace is T - 1 dependent loads, 0.35 us
+// each out of L2: 0.7 ms of a 5 ms sweep when one lane chases them in sequence.  The recursion therefore tracks, for every current
+// particle, the index of its ancestor at the last checkpoint time (one LDS gather per step) and files that map away every
+// C = ceil((T-1)/32) steps; after the final index is known, at most 32 LDS look-ups give the lineage's index at every checkpoint and
+// the segments in between are chased by 32 lanes in parallel.
+#define PG_DUO_CP 32
+struct DuoLineage {
+    uint16_t root[2][PGAS_SEG];          // step parity: index at the last checkpoint time of the lineage of particle i
+    uint16_t cp[PG_DUO_CP][PGAS_SEG];    // cp[k][i]: index at time k C of the lineage of particle i at time (k + 1) C
+    int at[PG_DUO_CP + 1];               // the sampled lineage's index at time k C
+};
+
+template <int NX, int D, int JIN, int J0T, int NR>
+__global__ __launch_bounds__(PG_BLK) void k_sweep_duo(DevModel md, const TransParams* __restrict__ tpp, const double* __restrict__ G_arg,
+                                                      const SweepParams* __restrict__ swp, const double* __restrict__ u_res,
+                                                      const double* __restrict__ u_anc, const double* __restrict__ m0L0,
+                                                      const double* __restrict__ ref, double* __restrict__ x_trace,
+                                                      int32_t* __restrict__ anc_trace, double* __restrict__ logw_last,
+                                                      double* __restrict__ logw_trace /* (T, N) or NULL */, UpperHdr* __restrict__ hdr,
+                                                      double* __restrict__ traj, const double* __restrict__ znoise, DuoShared* __restrict__ duo) {
+    __shared__ SmallSmem sm;
+    __shared__ DuoLineage lin;
+    extern __shared__ __attribute__((aligned(16))) double pg_g_lds_duo[];
+    const int tid = threadIdx.x;
+    const int N = md.N, T = md.T;
+    const size_t row = (size_t)N * NX;
+    const int C = T > 1 ? (T - 1 + PG_DUO_CP - 1) / PG_DUO_CP : 1;   // checkpoint interval: at most PG_DUO_CP blocks of steps
+    if (blockIdx.x == 0) {
+        // ================= workgroup 0: propagation (src/PGAS.py:45-77,130-134), particle i = r * 256 + tid
+        TransParams tp;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            tp.LS[q] = ld_const(&tpp->LS[q]);
+            tp.LSinv[q] = ld_const(&tpp->LSinv[q]);
+        }
+        tp.cS = ld_const(&tpp->cS);
+        tp.G = G_arg;
+        const uint64_t seed = ld_const(&swp->seed);
+        {
+            int gtot = NX;
+#pragma unroll
+            for (int d = 0; d < D; ++d) gtot *= (d == D - 1 && D > 1) ? JIN : md.J[d];
+            for (int i = tid; i < gtot; i += PG_BLK) pg_g_lds_duo[i] = G_arg[i];
+            lds_barrier();
+        }
+        double x[NR][NX];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = r * PG_BLK + tid;
+            double z[2];
+            pgas_rng_normals(seed, PGAS_STREAM_INIT, 0u, (uint64_t)(i < N ? i : N - 1), NX, z);
+#pragma unroll
+            for (int k = 0; k < NX; ++k) {
+                double v = m0L0[k];
+#pragma unroll
+                for (int l = 0; l <= k; ++l) v = PGAS_FMA(m0L0[NX + k * NX + l], z[l], v);
+                x[r][k] = (i == N - 1) ? ref[k] : v;
+                if (i < N) x_trace[(size_t)i * NX + k] = x[r][k];
+            }
+        }
+        double yn[PGAS_MAX_NY], rn[NX];
+        double2 zn[NR];
+        auto fetch = [&](int t) {
+#pragma unroll
+            for (int k = 0; k < PGAS_MAX_NY; ++k) yn[k] = k < md.ny ? md.y[(size_t)t * md.ny + k] : 0.0;
+#pragma unroll
+            for (int k = 0; k < NX; ++k) rn[k] = ref[(size_t)t * NX + k];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int i = r * PG_BLK + tid;
+                zn[r] = reinterpret_cast<const double2*>(znoise)[(size_t)t * N + (i < N ? i : N - 1)];
+            }
+        };
+        if (T > 1) fetch(1);
+        // A step is PUBLISHED one iteration late: by then its ring stores (and the trace stores in front of them in the in-order
+        // vmcnt queue) have had a whole step to complete, and the wait for them costs next to nothing.
+        auto publish = [&](int t) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave's slot stores have left
+            lds_barrier();
+            if (tid == 0) __hip_atomic_store(&duo->ready, t, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        };
+        for (int t = 1; t < T; ++t) {
+            const double* __restrict__ ut = md.u + (size_t)t * md.nu;
+            double yt[PGAS_MAX_NY], rf[NX];
+#pragma unroll
+            for (int k = 0; k < PGAS_MAX_NY; ++k) yt[k] = yn[k];
+#pragma unroll
+            for (int k = 0; k < NX; ++k) rf[k] = rn[k];
+            double2 zc[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) zc[r] = zn[r];
+            if (t > 1) publish(t - 1);
+            fetch(t + 1 < T ? t + 1 : t);
+            double la[NR], h[NR], ln[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int i = r * PG_BLK + tid;
+                double xin[1][NX], xt[NX];
+#pragma unroll
+                for (int k = 0; k < NX; ++k) xin[0][k] = x[r][k];
+                const double z[2] = {zc[r].x, zc[r].y};
+                small_particle_step<NX, D, JIN, J0T>(md, tp, pg_g_lds_duo, ut, yt, rf, md.p0 + i == md.Ng - 1, xin, z, xt, la[r], h[r], ln[r]);
+                if (i < N) {
+#pragma unroll
+                    for (int k = 0; k < NX; ++k) {
+                        x[r][k] = xt[k];
+                        st_stream(&x_trace[(size_t)t * row + (size_t)i * NX + k], xt[k]);
+                    }
+                }
+            }
+            // the slot of step t is free once the recursion has consumed step t - RING (one wave polls for all)
+            if (t > PG_DUO_RING) {
+                if (tid == 0)
+                    while (duo_poll(&duo->done) < t - PG_DUO_RING) __builtin_amdgcn_s_sleep(2);
+                lds_barrier();
+            }
+            double (&slot)[3][PGAS_SEG] = duo->ring[t & (PG_DUO_RING - 1)];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int i = r * PG_BLK + tid;
+                __hip_atomic_store(&slot[0][i], la[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slot[1][i], h[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&slot[2][i], ln[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (T > 1) publish(T - 1);
+        __threadfence();   // the state trace is in memory before the other workgroup chases ancestors through it
+        lds_barrier();
+        if (tid == 0) __hip_atomic_store(&duo->ready, T, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    // ================= workgroup 1: the weight recursion (src/PGAS.py:90-127,137-147), final index, back-trace
+    const bool pow2 = (N & (N - 1)) == 0;
+    const double invN = 1.0 / (double)N;
+    double logw[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        logw[r] = 0.0;
+        if (logw_trace != nullptr && r * PG_BLK + tid < N) logw_trace[r * PG_BLK + tid] = 0.0;
+    }
+    double u1n = T > 1 ? u_res[1] : 0.0, u2n = T > 1 ? u_anc[1] : 0.0;
+    int seen = 0;            // last value of the propagation's counter this workgroup has read: it runs ahead, so most steps need no poll
+    bool have_next = false;  // the next step's slot is already in registers (fetched while this step ran)
+    double nla[NR], nh[NR], nln[NR];
+    auto load_slot = [&](int t) {
+        const double (&slot)[3][PGAS_SEG] = duo->ring[t & (PG_DUO_RING - 1)];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = r * PG_BLK + tid;
+            nla[r] = __hip_atomic_load(&slot[0][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nh[r] = __hip_atomic_load(&slot[1][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nln[r] = __hip_atomic_load(&slot[2][i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    for (int t = 1; t < T; ++t) {
+        const double u1 = u1n, u2 = u2n;
+        u1n = u_res[t + 1 < T ? t + 1 : t];
+        u2n = u_anc[t + 1 < T ? t + 1 : t];
+        double U[NR];   // the data-independent half of the thresholds (a division when N is no power of two) before the wait
+#pragma unroll
+        for (int r = 0; r < NR; ++r) U[r] = slot_U(u1, r * PG_BLK + tid, N, invN, pow2);
+        if (!have_next) {
+            if (seen < t) {   // uniform
+                if (tid == 0) {
+                    int v;
+                    while ((v = duo_poll(&duo->ready)) < t) __builtin_amdgcn_s_sleep(1);
+                    sm.cnt[0] = v;
+                }
+                lds_barrier();
+                seen = sm.cnt[0];
+                lds_barrier();   // sm.cnt is reused by small_count
+            }
+            load_slot(t);
+        }
+        double lw[2][NR], ln[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = r * PG_BLK + tid;
+            const double la = nla[r], h = nh[r];
+            ln[r] = nln[r];
+            const double l1 = la + logw[r];   // src/PGAS.py:101-102
+            lw[0][r] = i < N ? l1 : -__builtin_inf();
+            lw[1][r] = i < N ? l1 + h : -__builtin_inf();   // :117-118
+            sm.la[i] = la;
+        }
+        // the next step's slot, if the propagation has already delivered it: its latency hides behind this step's scans
+        have_next = t + 1 < T && seen >= t + 1;
+        if (have_next) load_slot(t + 1);
+        double S[2];
+        small_scan<2, NR>(sm, lw, N, S);   // ends with a barrier: sm.num and sm.la are visible
+        const bool valid1 = (S[0] > 0.0) && (S[0] < __builtin_inf()), valid2 = (S[1] > 0.0) && (S[1] < __builtin_inf());
+        const int cnt2 = small_count<NR>(sm, sm.num[1], u2 * S[1]);
+        const int ref_idx = valid2 ? (cnt2 > N - 1 ? N - 1 : cnt2) : N - 1;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int i = r * PG_BLK + tid;
+            if (i < N) {
+                int a = i;   // no positive weight: identity (src/Filtering.py:25)
+                if (valid1) {
+                    const int p = small_lower_bound<NR * PG_BLK>(sm.num[0], U[r] * S[0]);
+                    a = p > N - 1 ? N - 1 : p;
+                }
+                if (i == N - 1) a = ref_idx;
+                anc_trace[(size_t)(t - 1) * N + i] = (int32_t)a;   // plain store: the back-trace of this very launch reads it (L2)
+                logw[r] = ln[r] - sm.la[a];   // src/PGAS.py:137-147
+                if (logw_trace != nullptr) logw_trace[(size_t)t * N + i] = logw[r];
+                // lineage: index at the last checkpoint time (k C, k = (t-1) / C) of particle i's ancestor
+                const uint16_t rt = ((t - 1) % C == 0) ? (uint16_t)a : lin.root[(t - 1) & 1][a];
+                lin.root[t & 1][i] = rt;
+                if (t % C == 0) lin.cp[t / C - 1][i] = rt;
+            }
+        }
+        lds_barrier();   // sm.la / sm.num are rewritten by the next step; every wave has read its ring slot
+        if (tid == 0) __hip_atomic_store(&duo->done, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- final index (src/PGAS.py:224-225) and back-trace (src/Filtering.py:40-55)
+    double lwf[1][NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int i = r * PG_BLK + tid;
+        lwf[0][r] = i < N ? logw[r] : -__builtin_inf();
+        if (i < N) logw_last[i] = logw[r];
+    }
+    double Sf[1];
+    small_scan<1, NR>(sm, lwf, N, Sf);
+    const bool validf = (Sf[0] > 0.0) && (Sf[0] < __builtin_inf());
+    const int cf = small_count<NR>(sm, sm.num[0], ld_const(&swp->u_final) * Sf[0]);
+    const int fidx = validf ? (cf > N - 1 ? N - 1 : cf) : N - 1;
+    __threadfence();   // this workgroup's ancestor stores
+    if (tid == 0) {
+        while (duo_poll(&duo->ready) < T) __builtin_amdgcn_s_sleep(1);   // the propagation has written and fenced the state trace
+        hdr->final_idx = fidx;
+        // the lineage's index at every checkpoint time, newest first: the running map covers the last (partial) block
+        const int kl = T > 1 ? (T - 2) / C : 0;   // block of the last step T - 1
+        lin.at[kl + 1] = fidx;
+        int b = T > 1 ? (int)lin.root[(T - 1) & 1][fidx] : fidx;
+        lin.at[kl] = b;
+        for (int k = kl - 1; k >= 0; --k) {
+            b = lin.cp[k][b];
+            lin.at[k] = b;
+        }
+    }
+    lds_barrier();
+    {
+        // segment k = times (k C, top], top = min((k + 1) C, T - 1), chased by lane k from the lineage's index at `top`
+        const int kl = T > 1 ? (T - 2) / C : 0;
+        if (tid <= kl && T > 1) {
+            const int k = tid, top = k == kl ? T - 1 : (k + 1) * C;
+            int b = lin.at[k + 1];
+            for (int t = top; t > k * C; --t) {
+#pragma unroll
+                for (int q = 0; q < NX; ++q) traj[(size_t)t * NX + q] = __hip_atomic_load(&x_trace[(size_t)t * row + (size_t)b * NX + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                b = __hip_atomic_load(&anc_trace[(size_t)(t - 1) * N + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (k == 0) {
+#pragma unroll
+                for (int q = 0; q < NX; ++q) traj[q] = __hip_atomic_load(&x_trace[(size_t)b * NX + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (T == 1 && tid == 0) {
+#pragma unroll
+            for (int q = 0; q < NX; ++q) traj[q] = __hip_atomic_load(&x_trace[(size_t)fidx * NX + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 }

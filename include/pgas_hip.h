@@ -170,7 +170,7 @@ int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 #define PGAS_OPT_SYRK_SPLITS 10 /* pgas_suffstats: number of row splits of the Z^T Z product (partial slabs summed in split order); 0 = automatic (about two workgroups per CU) */
 #define PGAS_OPT_TAIL_GROUPS 9 /* 1: single device only: the group scans ride in k_step's tail (in-launch hand-off to the workgroup that completes a group) instead of k_groups launches; measured slower, default 0 */
 #define PGAS_OPT_EVENT_STRIDE 8 /* k_propagate launches per event that gates the weight recursion's stream (default 8) */
-#define PGAS_OPT_SMALL_SWEEP 14 /* 1 (default): a context of at most one segment of particles (N <= 1024 -- the reference's own operating point is N = 200) runs the whole sweep, x_0 to back-trace, as ONE launch of ONE workgroup (k_sweep_small: states and log-weights in registers, both fixed-point CDFs, the auxiliary log-likelihoods and the exchange arrays in LDS; the propagation noise comes from one grid-wide launch in front of it) instead of ~3 dependent launches per time step; 0: the general multi-launch path at every size.  Bit-identical results */
+#define PGAS_OPT_SMALL_SWEEP 14 /* 1 (default): a context of at most one segment of particles (N <= 1024 -- the reference's own operating point is N = 200) runs the whole sweep, x_0 to back-trace, as ONE launch instead of ~3 dependent launches per time step: two workgroups (k_sweep_duo), one propagating every step ahead into a ring in device memory, the other running the weight recursion behind it with both fixed-point CDFs, the auxiliary log-likelihoods and the scan scratch in LDS; the propagation noise comes from one grid-wide launch in front of it.  2: the same work on one workgroup, all waves in lock step (k_sweep_small); 0: the general multi-launch path at every size.  Bit-identical results */
 #define PGAS_OPT_GRAPH 13 /* 1: pgas_sweep captures its launches (k_init ... k_backtrace, both streams) once in a HIP graph and replays it per sweep on an internal stream -- seed, uniforms, transition parameters, reference trajectory and result all live in device memory the graph's kernels read at execution time; same kernels, same order: identical results.  0: enqueue every launch (what profiled sweeps, the corrected mode and sharded sweeps always do).  Default: off -- on the HIP 7.0 runtime bundled with PyTorch 2.10 the replay measured slower than enqueueing at every size */
 #define PGAS_OPT_TRACE_BLOCK_BYTES 12 /* before the first sweep / pgas_shard_setup: keep the traces in row blocks of at most this many bytes (0 = default: one array per trace on an unsharded context, 1 GiB blocks on a shard); small values are a test knob that puts block boundaries inside short sweeps */
 #define PGAS_OPT_MNIW_VALU 6 /* 1: pgas_m_mniw_solve factorises column by column on the VALU instead of in MFMA-blocked panels (test knob) */

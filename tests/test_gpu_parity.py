@@ -97,6 +97,8 @@ def test_basis_init_step_bit_exact(name, N):
     ("smo", 200, {14: 0}), ("smo", 1024, {14: 0}), ("toy", 300, {14: 0}), ("emps", 500, {14: 0}), ("veh", 640, {14: 0}), ("smo", 777, {14: 0, 7: 1}), ("toy", 1, {14: 0}),
     ("smo", 256, {}), ("smo", 257, {}), ("toy", 1024, {}), ("emps27", 1000, {}), ("smo", 513, {13: 1, 14: 0}),
     ("emps", 250, {}), ("veh", 130, {}), ("veh27", 256, {}), ("toy", 255, {}), ("smo", 2, {}), ("smo", 63, {}),
+    # 14: 2 = the one-workgroup kernel (k_sweep_small) where the default is the two-workgroup pipeline (k_sweep_duo)
+    ("smo", 200, {14: 2}), ("toy", 1, {14: 2}), ("emps", 250, {14: 2}), ("smo", 1024, {14: 2}), ("veh27", 600, {14: 2}),
 ])
 def test_sweep_bit_exact(name, N, opts):
     pb, A, S, cm, csmc = _setup(name, N)

@@ -2,7 +2,7 @@
 //   d = fma(a[i][3], b[3][j], fma(a[i][2], b[2][j], fma(a[i][1], b[1][j], fma(a[i][0], b[0][j], c))))   (k ascending)
 // or to the descending one, or to neither?  Decides whether a matrix-core contraction can keep the canonical order of DESIGN.md 4.2.
 // Layout (gfx950, one wave): A: lane l holds A[i = l % 16][k = l / 16]; B: lane l holds B[k = l / 16][j = l % 16];
-// C/D: 4 values per lane, D[i = 4 * (l / 16) + r][j = l % 16], r = 0..3.
+// C/D: 4 values per lane, D[i = 4 * r + l / 16][j = l % 16], r = 0..3 (the layout csrc/pgas_suffstats.hip.h stores its accumulators with).
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -13,9 +13,9 @@ __global__ void k(const double* A, const double* B, const double* C, double* D) 
     const int l = threadIdx.x;
     const double a = A[(l % 16) * 4 + l / 16], b = B[(l / 16) * 16 + l % 16];
     d4 c;
-    for (int r = 0; r < 4; ++r) c[r] = C[(4 * (l / 16) + r) * 16 + l % 16];
+    for (int r = 0; r < 4; ++r) c[r] = C[(4 * r + l / 16) * 16 + l % 16];
     d4 d = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-    for (int r = 0; r < 4; ++r) D[(4 * (l / 16) + r) * 16 + l % 16] = d[r];
+    for (int r = 0; r < 4; ++r) D[(4 * r + l / 16) * 16 + l % 16] = d[r];
 }
 int main() {
     std::mt19937_64 g(7);
