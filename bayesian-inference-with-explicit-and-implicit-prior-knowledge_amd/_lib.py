@@ -533,7 +533,7 @@ class Engine:
         v = (C.c_int32 * 4)()
         self._chk(self.lib.pgas_get_launch_info(self._h, v), "pgas_get_launch_info")
         g = int(v[1]) & 15
-        return dict(chunk=int(v[0]), local_groups=g == 1, groups={0: "k_groups", 1: "local", 2: "tail", 3: "small"}[g], small=g == 3, graph=bool(int(v[1]) & 16), JP=int(v[2]), P=int(v[3]))
+        return dict(chunk=int(v[0]), local_groups=g == 1, groups={0: "k_groups", 1: "local", 2: "tail", 3: "small"}[g], small=g == 3, graph=bool(int(v[1]) & 16), mfma=bool(int(v[1]) & 32), JP=int(v[2]), P=int(v[3]))
 
     def shard_sweep(self, seed, ref, traj, propagate_chunk=0):
         self._ag_error = None

@@ -26,6 +26,9 @@
 #ifndef PG_W28
 #define PG_W28 2
 #endif
+#ifndef PG_WMX
+#define PG_WMX 2    // waves per SIMD the matrix-core k_propagate is compiled for
+#endif
 #ifndef PG_PPT3
 #define PG_PPT3 8   // particles per thread of the 3-D, nx = 2 variants (EMPS / Vehicle M = 729)
 #endif
@@ -92,6 +95,8 @@ struct DeviceGuard {
 typedef void (*front_fn)(DevModel, const TransParams*, int, uint64_t, const double*, const double*, const double*, int, double*, ScanBufs);
 typedef void (*backc_fn)(DevModel, const TransParams*, int, uint64_t, double, const double*, const double*, ScanBufs, Peers, int32_t*, double*, double*);
 typedef void (*prop_fn)(DevModel, const TransParams*, const double*, const SweepParams*, int, int, const double*, double*, const double*, double*, double*, double*);
+typedef void (*propmx_fn)(DevModel, const TransParams*, const double*, const SweepParams*, int, int, const double*, double*, const double*, double*, double*, double*,
+                          const MxInfo*, const double*);
 typedef void (*aux_fn)(DevModel, const TransParams*, int, const double*, double*);
 typedef void (*back_fn)(DevModel, int, double, const double*, ScanBufs, Peers, int32_t*, double*);
 typedef void (*init_fn)(DevModel, uint64_t, const SweepParams*, const double*, const double*, double*);
@@ -213,6 +218,11 @@ struct pgas_ctx {
     hipGraphExec_t graph_exec = nullptr;
     int graph_key[6] = {-1, -1, -1, -1, -1, -1};   // launch configuration the graph was captured with
     int last_graph = 0;            // 1: the last pgas_sweep replayed the captured graph
+    // 3-D, nx = 2, innermost extent 12 (EMPS / Vehicle M = 729): k_propagate's contraction on the f64 matrix cores (PGAS_OPT_MFMA_PROPAGATE)
+    MxInfo* d_mxi = nullptr;       // tile descriptor + gather indices of the operand image
+    double* d_gimg = nullptr;      // the image (k_pack_mx, per parameter set)
+    int mx_slots = 0;
+    int use_mx = 0;                // measured slower than the vector form (126 vs 114 us per step): opt-in
     int use_small = 1;             // PGAS_OPT_SMALL_SWEEP: contexts of at most one segment run the whole sweep in one workgroup (k_sweep_small)
     int last_small = 0;            // 1: the last pgas_sweep did
     double* d_znoise = nullptr;    // (T, N, 2) propagation noise of a single-workgroup sweep (k_small_noise)
@@ -416,6 +426,41 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
         HIPCHK(c, hipMalloc(&c->d_qdesc, qd.size() * sizeof(uint64_t)));
         HIPCHK(c, hipMemcpy(c->d_qdesc, qd.data(), qd.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
         md.qdesc = c->d_qdesc;
+        if (d->nx == 2 && md.JP == 12 && md.J[0] <= 12) {
+            // matrix-core form of the contraction (eval_mean_mx): pair ci = outermost frequencies (2 ci, 2 ci + 1), tile tau = b in
+            // [4 tau, 4 tau + 4); a tile runs as many K steps (of 4 innermost frequencies) as its longest row needs
+            // The kernel is compiled for ONE descriptor, PG_MX_DESC_BALL729 (every 729-function basis of the reference); a model whose tiles
+            // need no more K steps than that anywhere runs on it (extra K steps multiply zeros), any other keeps the vector form.
+            std::vector<MxInfo> mi(1);
+            MxInfo& m = mi[0];
+            m.desc = PG_MX_DESC_BALL729; m.nslots = 0; m.pad = 0;
+            const int J0 = md.J[0], J1 = md.J[1];
+            bool fits = true;
+            for (int ci = 0; ci < 6; ++ci) {
+                int nks[3] = {0, 0, 0};
+                for (int tau = 0; tau < 3; ++tau) {
+                    int need = 0;
+                    for (int a = 2 * ci; a < 2 * ci + 2 && a < J0; ++a)
+                        for (int b = 4 * tau; b < 4 * tau + 4 && b < J1; ++b) need = std::max(need, (ql[(size_t)a * J1 + b] + 3) / 4);
+                    nks[tau] = mx_nk(PG_MX_DESC_BALL729, 3 * ci + tau);
+                    fits = fits && need <= nks[tau];
+                }
+                for (int tau = 0; tau < 3; ++tau)       // the order eval_mean_mx issues its MFMAs in
+                    for (int ks = 0; ks < nks[tau]; ++ks) {
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int i = lane % 16, q = 4 * ks + lane / 16, g = i % 4, b = 4 * tau + i / 4, a = 2 * ci + g / 2, k = g % 2;
+                            m.idx[m.nslots * 64 + lane] = (a < J0 && b < J1) ? (int32_t)((((size_t)a * J1 + b) * md.JP + q) * 2 + k) : -1;
+                        }
+                        ++m.nslots;
+                    }
+            }
+            if (fits) {
+                c->mx_slots = m.nslots;
+                HIPCHK(c, hipMalloc(&c->d_mxi, sizeof(MxInfo)));
+                HIPCHK(c, hipMemcpy(c->d_mxi, &m, sizeof(MxInfo), hipMemcpyHostToDevice));
+                HIPCHK(c, hipMalloc(&c->d_gimg, (size_t)m.nslots * 64 * sizeof(double)));
+            }
+        }
     }
     c->gtotal = gsize * d->nx;
     HIPCHK(c, hipMalloc(&c->d_G, c->gtotal * sizeof(double)));
@@ -442,6 +487,7 @@ static int create_impl(const pgas_model_desc* d, pgas_ctx* c) {
     HIPCHK(c, hipMalloc(&c->d_refbuf, (size_t)d->T * d->nx * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->d_trajbuf, (size_t)d->T * d->nx * sizeof(double)));
     { const char* e = getenv("PGAS_GRAPH"); if (e && (e[0] == '0' || e[0] == '1')) c->use_graph = e[0] - '0'; }   // development knob
+    { const char* e = getenv("PGAS_MFMA_PROPAGATE"); if (e && (e[0] == '0' || e[0] == '1')) c->use_mx = e[0] - '0'; }   // development knob (A/B runs)
     for (int i = 0; i < 2; ++i) {
         int rc = alloc_scanbufs(c, &c->sb[i]);
         if (rc) return rc;
@@ -470,7 +516,7 @@ int pgas_create(const pgas_model_desc* desc, pgas_ctx** out) {
 void pgas_destroy(pgas_ctx* c) {
     if (!c) return;
     DeviceGuard guard(c->device);
-    hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_qdesc); hipFree(c->d_m0L0); hipFree(c->d_ref);
+    hipFree(c->d_y); hipFree(c->d_u); hipFree(c->d_idx); hipFree(c->d_pos); hipFree(c->d_qdesc); hipFree(c->d_mxi); hipFree(c->d_gimg); hipFree(c->d_m0L0); hipFree(c->d_ref);
     if (c->graph_exec) (void)hipGraphExecDestroy(c->graph_exec);
     if (c->graph) (void)hipGraphDestroy(c->graph);
     if (c->ev_g0) (void)hipEventDestroy(c->ev_g0);
@@ -501,6 +547,10 @@ static int pack_params(pgas_ctx* c, const double* A_dev, const double* S_dev, hi
     const int64_t n = (int64_t)c->md.M * c->md.nx;
     hipLaunchKernelGGL(k_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, A_dev, c->d_pos, c->md.M, c->md.nx, c->md.nrm, c->d_G, c->gtotal, c->tp, S_dev, c->d_tp);
     KCHK(c, "k_pack");
+    if (c->d_mxi) {
+        hipLaunchKernelGGL(k_pack_mx, dim3((unsigned)((c->mx_slots * 64 + 255) / 256)), dim3(256), 0, st, (const double*)c->d_G, (const MxInfo*)c->d_mxi, c->d_gimg);
+        KCHK(c, "k_pack_mx");
+    }
     c->have_params = true;
     return PGAS_OK;
 }
@@ -792,7 +842,10 @@ static int launch_propagate(pgas_ctx* c, int t0, int t1, const double* ref_dev, 
     const int spw = c->var.PPT / PG_PPT;   // segments per k_propagate workgroup
     const dim3 grid((c->md.nseg + spw - 1) / spw), blk(PG_BLK);
     size_t lds = c->overlap ? c->prop_lds : 0;
-    if (c->md.D == 3) {   // the LDS copy of the coefficient tensor (k_propagate, 3-D variants)
+    const bool mx = c->d_mxi && c->use_mx;
+    if (mx) {   // operand image + one transposed sine table per wave
+        lds = (size_t)c->mx_slots * 64 * sizeof(double) + (size_t)(PG_BLK / 64) * 64 * PG_MX_TSTRIDE * sizeof(double);
+    } else if (c->md.D == 3) {   // the LDS copy of the coefficient tensor (k_propagate, 3-D variants)
         const size_t need = (size_t)c->gtotal * sizeof(double);
         if (need > 64 * 1024) FAIL(c, PGAS_E_ARG, "k_propagate: coefficient tensor of %zu bytes does not fit the LDS budget", need);
         lds = lds > need ? lds : need;
@@ -803,6 +856,7 @@ static int launch_propagate(pgas_ctx* c, int t0, int t1, const double* ref_dev, 
     for (int ta = t0; ta < t1;) {
         const int tb = std::min(t1, ((ta >> sh) + 1) << sh);
         const prop_fn prop = (tb == ta + 1 && c->var.prop_one) ? c->var.prop_one : c->var.prop;
+        const propmx_fn pmx = tb == ta + 1 ? k_propagate_mx<2, 12, PG_WMX, PG_PPT3, true, PG_MX_DESC_BALL729> : k_propagate_mx<2, 12, PG_WMX, PG_PPT3, false, PG_MX_DESC_BALL729>;
         const double* x_prev = (const double*)c->rs[PG_RB_X].row(ta - 1);
         double* x_rows = (double*)c->rs[PG_RB_X].row(ta);
         double* la = (double*)c->rs[PG_RB_LA].row(ta);
@@ -815,9 +869,16 @@ static int launch_propagate(pgas_ctx* c, int t0, int t1, const double* ref_dev, 
                 c->evp.push_back(e);
             }
             // start/stop events bound to the dispatch itself: they carry the kernel's own begin/end timestamps
+            if (mx)
+                hipExtLaunchKernelGGL(pmx, grid, blk, lds, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, c->md, (const TransParams*)c->d_tp,
+                                      (const double*)c->d_G, (const SweepParams*)c->d_sp, ta, tb, x_prev, x_rows, ref_dev, la, h, ln, (const MxInfo*)c->d_mxi, (const double*)c->d_gimg);
+            else
             hipExtLaunchKernelGGL(prop, grid, blk, lds, st, c->evp[c->evp_used], c->evp[c->evp_used + 1], 0, c->md, (const TransParams*)c->d_tp,
                                   (const double*)c->d_G, (const SweepParams*)c->d_sp, ta, tb, x_prev, x_rows, ref_dev, la, h, ln);
             c->evp_used += 2;
+        } else if (mx) {
+            hipLaunchKernelGGL(pmx, grid, blk, lds, st, c->md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp, ta, tb, x_prev, x_rows, ref_dev, la, h, ln,
+                               (const MxInfo*)c->d_mxi, (const double*)c->d_gimg);
         } else {
             hipLaunchKernelGGL(prop, grid, blk, lds, st, c->md, (const TransParams*)c->d_tp, (const double*)c->d_G, (const SweepParams*)c->d_sp, ta, tb, x_prev, x_rows, ref_dev, la, h, ln);
         }
@@ -1218,6 +1279,11 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         c->prop_lds = (int)value;
         return PGAS_OK;
     }
+    if (option == PGAS_OPT_MFMA_PROPAGATE) {
+        if (value < 0 || value > 1) FAIL(c, PGAS_E_ARG, "pgas_set_option: PGAS_OPT_MFMA_PROPAGATE takes 0 or 1");
+        c->use_mx = (int)value;
+        return PGAS_OK;
+    }
     if (option == PGAS_OPT_SMALL_SWEEP) {
         if (value < 0 || value > 2) FAIL(c, PGAS_E_ARG, "pgas_set_option: PGAS_OPT_SMALL_SWEEP takes 0, 1 or 2");
         c->use_small = (int)value;
@@ -1277,7 +1343,7 @@ int pgas_get_launch_info(pgas_ctx* c, int32_t* info4) {
     if (!c) return PGAS_E_ARG;
     if (!info4) FAIL(c, PGAS_E_ARG, "pgas_get_launch_info: NULL argument");
     info4[0] = c->last_chunk;
-    info4[1] = (c->last_small ? 3 : (sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0))) + (c->last_graph ? 16 : 0);   // + 16: the last sweep replayed the captured graph
+    info4[1] = (c->last_small ? 3 : (sweep_is_local(c) ? 1 : (sweep_tail_groups(c) ? 2 : 0))) + (c->last_graph ? 16 : 0) + ((c->d_mxi && c->use_mx && !c->last_small) ? 32 : 0);   // + 16: the last sweep replayed the captured graph; + 32: k_propagate ran its matrix-core form
     info4[2] = c->md.JP;
     info4[3] = c->var_P;
     return PGAS_OK;

@@ -585,6 +585,144 @@ __device__ __forceinline__ void eval_mean(const DevModel& md, const double* __re
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The 3-D contraction on the f64 matrix cores (k_propagate<..., MX>; nx = 2, innermost extent 12, J[0], J[1] <= 12: the
+// 729-function bases of EMPS / Vehicle).  v_mfma_f64_16x16x4_f64 accumulates its four products as the ascending chain
+// acc = fma(a_k, b_k, acc), k = 0..3 (tools/probes/mfma_f64_probe.hip: 200 of 200 random trials bit-identical on gfx950), which IS
+// the canonical order of the innermost sum in = sum_q G[a][b][q][k] tab[q] (q ascending) -- up to the sign of an
+// exact zero (the vector form starts with a product, the matrix form from +0), which cannot reach `mid` (mid starts at +0 and
+// +0 + (-0) = +0).  So stage 1 runs as MFMA tiles and stages 2 / 3 (the sums over b and a, with their sine recurrences) stay
+// scalar chains in the canonical order: the same bits as eval_mean.
+//
+// Geometry of one MFMA (A: lane l holds A[l % 16][l / 16], B: lane l holds B[l / 16][l % 16], D: lane l holds D[4 r + l / 16][l % 16]):
+//   columns = 16 particles (sub-batch s of the wave's 64), K = 4 innermost frequencies (step ks of 3), rows = 16 (a, b, k) triples.
+//   Tile (ci, tau) carries rows i = 4 (b - 4 tau) + g with lane group g = l / 16 of the RESULT owning (a = 2 ci + g / 2, k = g % 2):
+//   after the tiles tau = 0, 1, 2 of pair ci, lane (g, n) holds in[a][b][k], b = 0..11, of particle 16 s + n in 12 accumulator
+//   registers with constant indices -- exactly one b-chain.  The ball-shaped index set (MxInfo::desc: K steps per tile) lets most
+//   tiles stop after 1 or 2 K steps and some vanish: 35 MFMAs per 16 particles at M = 729 instead of the dense 54.
+// The operands: A from an image of the coefficient tensor in LDS (k_pack_mx writes it per parameter set, one 512-byte row per MFMA),
+// B from a per-wave transposed table of the innermost sines in LDS; the recurrence starts of the two outer dimensions travel by
+// ds_bpermute; stage 3 pairs lane groups g and g + 2 (a = 2 ci, 2 ci + 1: ascending a).
+#define PG_MX_MAXSLOTS 54   // 6 pairs x 3 tiles x 3 K steps
+#define PG_MX_TSTRIDE 13    // doubles per particle of the transposed sine table (12 + 1: conflict-free columns)
+struct MxInfo {
+    uint64_t desc;        // 2 bits per (pair ci, tile tau) at bit 6 ci + 2 tau: K steps of that tile (0..3)
+    int32_t nslots, pad;  // MFMAs per sub-batch = rows of the image
+    int32_t idx[PG_MX_MAXSLOTS * 64];   // element of the packed tensor G behind image entry (slot, lane); -1: zero
+};
+typedef double pg_d4 __attribute__((ext_vector_type(4)));
+
+__global__ void k_pack_mx(const double* __restrict__ G, const MxInfo* __restrict__ mi, double* __restrict__ img) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < mi->nslots * 64) {
+        const int j = mi->idx[i];
+        img[i] = j >= 0 ? G[j] : 0.0;
+    }
+}
+
+// K steps of tile i = 3 ci + tau under descriptor `desc`, and the image row of its first MFMA
+__host__ __device__ constexpr int mx_nk(uint64_t desc, int i) { return (int)((desc >> (2 * i)) & 3u); }
+__host__ __device__ constexpr int mx_slot(uint64_t desc, int i) {
+    int n = 0;
+    for (int j = 0; j < i; ++j) n += mx_nk(desc, j);
+    return n;
+}
+// The tile descriptor is a COMPILE-TIME constant (like the FAST shapes above): with the K-step counts known, a sub-batch is straight-line
+// code -- 35 MFMAs at M = 729 with the image rows at immediate offsets, the b-chains between them -- instead of 54 uniform branches
+// (measured: the branchy form ran at 179 us per step against 114 us for the vector form).
+#define PG_MX_DESC_BALL729 0x4a6efbefull   // the 729-function ball of the 11 x 11 x 11 grid (EMPS and Vehicle: src/EMPS.py:101-113)
+template <int NX, int JIN, uint64_t DESC>
+__device__ __forceinline__ void eval_mean_mx(const DevModel& md, const double* __restrict__ aimg, double* __restrict__ tabT,
+                                             const double* __restrict__ ut, const double (&x)[NX], double (&aux)[NX]) {
+    static_assert(NX == 2 && JIN == 12, "instantiated for the 729-function bases");
+    const int lane = threadIdx.x & 63, n = lane & 15, g = lane >> 4;
+    Cheb c0, c1;
+    {
+        double r2[1] = {basis_arg<NX, 2, false>(md, x, ut)}, r0[1] = {basis_arg<NX, 0, false>(md, x, ut)}, r1[1] = {basis_arg<NX, 1, false>(md, x, ut)};
+        DimStart d2[1], d0[1], d1[1];
+        dim_start_n<1>(md, 2, r2, d2);
+        dim_start_n<1>(md, 0, r0, d0);
+        dim_start_n<1>(md, 1, r1, d1);
+        Cheb ci = cheb_init(md, 2, d2[0]);
+#pragma unroll
+        for (int q = 0; q < JIN; ++q) {
+            tabT[lane * PG_MX_TSTRIDE + q] = ci.cur;
+            cheb_next(ci);
+        }
+        c0 = cheb_init(md, 0, d0[0]);
+        c1 = cheb_init(md, 1, d1[0]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the table is read by other lanes of this wave only: program order is enough
+    __builtin_amdgcn_wave_barrier();
+    const int J0 = md.J[0];
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+        const int src = 16 * s + n;   // the particle (lane of this wave) whose column this lane holds in sub-batch s
+        double B[3];
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) B[ks] = tabT[src * PG_MX_TSTRIDE + 4 * ks + g];
+        Cheb e0, e1;
+        e0.cur = __shfl(c0.cur, src); e0.prev = __shfl(c0.prev, src); e0.tw = __shfl(c0.tw, src);
+        e1.cur = __shfl(c1.cur, src); e1.prev = __shfl(c1.prev, src); e1.tw = __shfl(c1.tw, src);
+        // The MFMAs of a sub-batch are one stream over the image's rows (slot = 0, 1, ...): row slot + 1 is fetched while MFMA `slot`
+        // runs; the tiles come in (ci, tau) order, each with its own K-step count, and the b-chain of tile i is issued AFTER the
+        // MFMAs of tile i + 1 so that the matrix core works while the vector ALU adds.
+        const double* __restrict__ ap = aimg + lane;
+        pg_d4 acc[2];
+        auto tile = [&](const int i, pg_d4& d) {   // i is a constant after unrolling: bit position 6 ci + 2 tau = 2 (3 ci + tau)
+            const int nk = mx_nk(DESC, i), s0 = mx_slot(DESC, i);
+            d = pg_d4{0.0, 0.0, 0.0, 0.0};
+            if (nk > 0) d = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[(s0 + 0) * 64], B[0], d, 0, 0, 0);
+            if (nk > 1) d = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[(s0 + 1) * 64], B[1], d, 0, 0, 0);
+            if (nk > 2) d = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[(s0 + 2) * 64], B[2], d, 0, 0, 0);
+        };
+        double midv[6];
+        double sa = 0.0, sb = 0.0, mid = 0.0;
+        tile(0, acc[0]);
+#pragma unroll
+        for (int i = 0; i < 18; ++i) {
+            const int ci = i / 3, tau = i % 3;
+            if (i + 1 < 18) tile(i + 1, acc[(i + 1) & 1]);
+            // stage 2: mid = sum_b s1[b] in[b], b ascending, the recurrence of eval_mean (s1[b+1] = tw s1[b] - s1[b-1]); tiles behind
+            // the last one with coefficients are skipped (their rows are zeros: mid + s 0 = mid)
+            if (tau == 0) {
+                sa = e1.prev; sb = e1.cur; mid = 0.0;
+            }
+            if ((((unsigned)(DESC >> (6 * ci)) & 63u) >> (2 * tau)) != 0u) {
+                const pg_d4 d = acc[i & 1];
+                mid = PGAS_FMA(sb, d[0], mid);
+                sa = PGAS_FMA(e1.tw, sb, -sa);
+                mid = PGAS_FMA(sa, d[1], mid);
+                sb = PGAS_FMA(e1.tw, sa, -sb);
+                mid = PGAS_FMA(sb, d[2], mid);
+                sa = PGAS_FMA(e1.tw, sb, -sa);
+                mid = PGAS_FMA(sa, d[3], mid);
+                sb = PGAS_FMA(e1.tw, sa, -sb);
+            }
+            if (tau == 2) midv[ci] = mid;
+        }
+        // stage 3 on lane groups 0 / 1 (k = g): aux = sum_a s0[a] mid[a], a ascending = own pair member, then group g + 2's
+        double al = 0.0;
+#pragma unroll
+        for (int ci = 0; ci < 6; ++ci) {
+            const double other = __shfl_xor(midv[ci], 32);
+            if (2 * ci < J0) {
+                al = PGAS_FMA(e0.cur, midv[ci], al);
+                cheb_next(e0);
+            }
+            if (2 * ci + 1 < J0) {
+                al = PGAS_FMA(e0.cur, other, al);
+                cheb_next(e0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NX; ++k) {
+            const double v = __shfl(al, k * 16 + n);
+            if (g == s) aux[k] = v;
+        }
+    }
+}
+
 // sines of every frequency of dimension d for ONE point (test hook / trajectory basis): s[q], q < J[d]
 template <int NX>
 __device__ __forceinline__ void dim_sines_point(const DevModel& md, int d, const double (&xv)[NX], const double* __restrict__ ut,
@@ -989,13 +1127,12 @@ __global__ __launch_bounds__(PG_BLK) void k_front(DevModel md, const TransParams
 // One group of P particles of this thread through one time step, start to finish (basis, transition mean, noise, the three
 // log-densities, new state): the FAST k_propagate walks its PG_PPT particles group by group so that only one group's
 // intermediates are live at a time (the all-at-once form needs ~165 VGPRs, this one fits four waves per SIMD).
-template <int NX, int D, int JIN, int P, int J0T>
-__device__ __forceinline__ void propagate_group(const DevModel& md, const TransParams& tp, const double* G, int t, uint64_t seed, const double (&rf)[NX],
-                                                const double* __restrict__ yt, const double* __restrict__ ut, int seg, int r0,
-                                                const double (&xin)[P][NX], double (&xn)[P][NX], double (&la)[P], double (&h)[P], double (&ln)[P]) {
+// everything of a group's step after the transition means: noise, the three log-densities, the new states
+template <int NX, int P>
+__device__ __forceinline__ void propagate_finish(const DevModel& md, const TransParams& tp, int t, uint64_t seed, const double (&rf)[NX],
+                                                 const double* __restrict__ yt, int seg, int r0, const double (&aux)[P][NX],
+                                                 double (&xn)[P][NX], double (&la)[P], double (&h)[P], double (&ln)[P]) {
     const int tid = threadIdx.x;
-    double aux[P][NX];
-    eval_mean<NX, D, JIN, P, J0T>(md, G, ut, xin, aux);
     double z0[P], z1[P];
     {
         pgas_u32x4 w[P];
@@ -1030,18 +1167,29 @@ __device__ __forceinline__ void propagate_group(const DevModel& md, const TransP
         ln[p] = loglik<NX>(md, yt, xn[p]);
     }
 }
+template <int NX, int D, int JIN, int P, int J0T>
+__device__ __forceinline__ void propagate_group(const DevModel& md, const TransParams& tp, const double* G, int t, uint64_t seed, const double (&rf)[NX],
+                                                const double* __restrict__ yt, const double* __restrict__ ut, int seg, int r0,
+                                                const double (&xin)[P][NX], double (&xn)[P][NX], double (&la)[P], double (&h)[P], double (&ln)[P]) {
+    double aux[P][NX];
+    eval_mean<NX, D, JIN, P, J0T>(md, G, ut, xin, aux);
+    propagate_finish<NX, P>(md, tp, t, seed, rf, yt, seg, r0, aux, xn, la, h, ln);
+}
 
 // PPT = particles per thread: PPT / 4 segments per workgroup, grid = ceil(nseg / (PPT / 4)).  A thread walks its particles in
 // groups of P (propagate_group).  Measured on the SingleMassOscillator sweep: PPT = 8 (512 workgroups at N = 2^20, all resident
 // at once) beats 4 by 6-9 % when the weight recursion runs beside it.
 // ONE = the launch covers exactly one time step (t1 == t0 + 1; what the sweep uses for the cheap bases): a group's state is then
 // loaded right before its pass instead of being held for the whole launch (8 particles x 2 doubles = 32 VGPRs less).
-template <int NX, int D, int JIN, int P, int J0T, int PPT, bool ONE>
+// MX: the 3-D contraction on the matrix cores (eval_mean_mx above; P == 1: a wave's 64 particles per pass): `mxi` = the tile
+// descriptor, `gimg` = the MFMA-operand image of the coefficient tensor (k_pack_mx).
+template <int NX, int D, int JIN, int P, int J0T, int PPT, bool ONE, uint64_t MXD = 0>
 __device__ __forceinline__ void propagate_kernel(const DevModel& md, const TransParams* __restrict__ tpp, const double* __restrict__ G_arg, const SweepParams* __restrict__ swp, int t0, int t1,
                                                  const double* __restrict__ x_prev /* row t0-1 */, double* __restrict__ x_rows /* rows t0 ... */,
                                                  const double* __restrict__ ref,
                                                  double* __restrict__ la_rows, double* __restrict__ h_rows,
-                                                 double* __restrict__ ln_rows /* rows t0 ... of the hand-off buffers */) {
+                                                 double* __restrict__ ln_rows /* rows t0 ... of the hand-off buffers */,
+                                                 const MxInfo* __restrict__ mxi = nullptr, const double* __restrict__ gimg = nullptr) {
     const int tid = threadIdx.x;
     // Device-resident parameters (a replayed graph sees the current ones), read through the constant address space: nothing writes them
     // while the kernel runs.  The coefficient tensor's ADDRESS stays a kernel argument: taken from memory (tp.G), the tensor's scalar
@@ -1061,7 +1209,17 @@ __device__ __forceinline__ void propagate_kernel(const DevModel& md, const Trans
     // and read from there with wave-uniform (broadcast) addresses: per row of the frequency grid the scalar-load path would stall
     // on a fresh s_load (24 coefficients for 48 FMAs), LDS reads pipeline behind the FMAs.
     const double* Guse = tp.G;
-    if constexpr (D == 3) {
+    double* mx_tab = nullptr;
+    constexpr bool MX = MXD != 0;
+    if constexpr (MX) {
+        static_assert(D == 3 && P == 1, "matrix-core contraction: 3-D bases, one particle per lane and pass");
+        extern __shared__ __attribute__((aligned(16))) double pg_g_lds[];
+        const int nimg = ld_const(&mxi->nslots) * 64;
+        for (int i = tid; i < nimg; i += PG_BLK) pg_g_lds[i] = gimg[i];
+        __syncthreads();
+        Guse = pg_g_lds;
+        mx_tab = pg_g_lds + nimg + (tid >> 6) * (64 * PG_MX_TSTRIDE);
+    } else if constexpr (D == 3) {
         extern __shared__ __attribute__((aligned(16))) double pg_g_lds[];
         const int gtot = md.J[0] * md.J[1] * JIN * NX;
         for (int i = tid; i < gtot; i += PG_BLK) pg_g_lds[i] = tp.G[i];
@@ -1125,7 +1283,13 @@ __device__ __forceinline__ void propagate_kernel(const DevModel& md, const Trans
 #pragma unroll
                     for (int p = 0; p < P; ++p) load_state(rn + p, xnext[p]);
                 }
-                propagate_group<NX, D, JIN, P, J0T>(md, tp, Guse, t, seed, rf, yt, ut, seg0 + r0 / PG_PPT, r0 % PG_PPT, xin, xn, la, h, ln);
+                if constexpr (MX) {
+                    double aux[P][NX];
+                    eval_mean_mx<NX, JIN, MXD>(md, Guse, mx_tab, ut, xin[0], aux[0]);
+                    propagate_finish<NX, P>(md, tp, t, seed, rf, yt, seg0 + r0 / PG_PPT, r0 % PG_PPT, aux, xn, la, h, ln);
+                } else {
+                    propagate_group<NX, D, JIN, P, J0T>(md, tp, Guse, t, seed, rf, yt, ut, seg0 + r0 / PG_PPT, r0 % PG_PPT, xin, xn, la, h, ln);
+                }
 #pragma unroll
                 for (int p = 0; p < P; ++p) {
                     const size_t pi = particle(r0 + p);   // la / h / ln are padded to nseg*SEG
@@ -1167,6 +1331,13 @@ __global__ __launch_bounds__(PG_BLK, W) void k_propagate(DevModel md, const Tran
                                                           const double* __restrict__ x_prev, double* __restrict__ x_rows, const double* __restrict__ ref,
                                                           double* __restrict__ la_rows, double* __restrict__ h_rows, double* __restrict__ ln_rows) {
     propagate_kernel<NX, D, JIN, P, J0T, PPT, ONE>(md, tpp, G, swp, t0, t1, x_prev, x_rows, ref, la_rows, h_rows, ln_rows);
+}
+template <int NX, int JIN, int W, int PPT, bool ONE, uint64_t MXD>
+__global__ __launch_bounds__(PG_BLK, W) void k_propagate_mx(DevModel md, const TransParams* __restrict__ tpp, const double* __restrict__ G, const SweepParams* __restrict__ swp, int t0, int t1,
+                                                             const double* __restrict__ x_prev, double* __restrict__ x_rows, const double* __restrict__ ref,
+                                                             double* __restrict__ la_rows, double* __restrict__ h_rows, double* __restrict__ ln_rows,
+                                                             const MxInfo* __restrict__ mxi, const double* __restrict__ gimg) {
+    propagate_kernel<NX, 3, JIN, 1, 0, PPT, ONE, MXD>(md, tpp, G, swp, t0, t1, x_prev, x_rows, ref, la_rows, h_rows, ln_rows, mxi, gimg);
 }
 // ------------------------------------------------------------------------------------------
 // k_segscan: softmax scan of a plain weight vector (final index draw, src/PGAS.py:224)

@@ -149,8 +149,8 @@ int pgas_get_profile(pgas_ctx* ctx, int64_t* resample_launches, double* resample
                      double* propagate_ms, void* stream);
 /* What the last sweep launched: info4 = {time steps per k_propagate launch, group-scan placement (0: k_groups launches between the
  * steps, 1: k_step<LOCAL> scans all groups in every workgroup, 2: in k_step's tail by the workgroup that completes a group, 3: no group
- * scans at all -- the single-workgroup sweep k_sweep_small ran; + 16 when
- * the last sweep replayed the captured HIP graph),
+ * scans at all -- the one-launch small sweep (k_sweep_duo / k_sweep_small) ran; + 16 when
+ * the last sweep replayed the captured HIP graph; + 32 when k_propagate ran its matrix-core form, PGAS_OPT_MFMA_PROPAGATE),
  * padded innermost basis extent JP, particles per basis pass P} -- bench.py labels its kernels from this. */
 int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 
@@ -171,6 +171,7 @@ int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 #define PGAS_OPT_TAIL_GROUPS 9 /* 1: single device only: the group scans ride in k_step's tail (in-launch hand-off to the workgroup that completes a group) instead of k_groups launches; measured slower, default 0 */
 #define PGAS_OPT_EVENT_STRIDE 8 /* k_propagate launches per event that gates the weight recursion's stream (default 8) */
 #define PGAS_OPT_SMALL_SWEEP 14 /* 1 (default): a context of at most one segment of particles (N <= 1024 -- the reference's own operating point is N = 200) runs the whole sweep, x_0 to back-trace, as ONE launch instead of ~3 dependent launches per time step: two workgroups (k_sweep_duo), one propagating every step ahead into a ring in device memory, the other running the weight recursion behind it with both fixed-point CDFs, the auxiliary log-likelihoods and the scan scratch in LDS; the propagation noise comes from one grid-wide launch in front of it.  2: the same work on one workgroup, all waves in lock step (k_sweep_small); 0: the general multi-launch path at every size.  Bit-identical results */
+#define PGAS_OPT_MFMA_PROPAGATE 15 /* 1: models with a 3-D basis, n_x = 2 and the 729-function index ball of the 11 x 11 x 11 grid (EMPS / Vehicle, src/EMPS.py:101-113) run the innermost sum of k_propagate's contraction A phi(x) (src/PGAS.py:52-55) on v_mfma_f64_16x16x4_f64, whose four-term accumulation is the canonical ascending fma chain: bit-identical to the vector-ALU form.  Default 0: on MI355X the f64 MFMA occupies the SIMD's vector pipeline (no overlap with vector fp64 work, tools/probes/mfma_valu_overlap_probe.hip) and the padded tiles carry 1.5x the flops: 126 against 114 us per step */
 #define PGAS_OPT_GRAPH 13 /* 1: pgas_sweep captures its launches (k_init ... k_backtrace, both streams) once in a HIP graph and replays it per sweep on an internal stream -- seed, uniforms, transition parameters, reference trajectory and result all live in device memory the graph's kernels read at execution time; same kernels, same order: identical results.  0: enqueue every launch (what profiled sweeps, the corrected mode and sharded sweeps always do).  Default: off -- on the HIP 7.0 runtime bundled with PyTorch 2.10 the replay measured slower than enqueueing at every size */
 #define PGAS_OPT_TRACE_BLOCK_BYTES 12 /* before the first sweep / pgas_shard_setup: keep the traces in row blocks of at most this many bytes (0 = default: one array per trace on an unsharded context, 1 GiB blocks on a shard); small values are a test knob that puts block boundaries inside short sweeps */
 #define PGAS_OPT_MNIW_VALU 6 /* 1: pgas_m_mniw_solve factorises column by column on the VALU instead of in MFMA-blocked panels (test knob) */

@@ -91,6 +91,8 @@ def test_basis_init_step_bit_exact(name, N):
     ("smo", 5000, {12: 1 << 18}),     # PGAS_OPT_TRACE_BLOCK_BYTES: traces in row blocks (2 state rows, 4 hand-off rows, 8 ancestor rows per block)
     ("smo", 70000, {12: 4 << 20, 1: 7}),   # ... with k_propagate chunks of 7 steps that straddle block boundaries (split launches)
     ("emps", 2048, {12: 1 << 17}),    # ... 3-D basis, 4 state rows per block
+    # PGAS_OPT_MFMA_PROPAGATE = 1: the 3-D contraction's innermost sum on the f64 matrix cores (default: vector ALUs); odd segment counts, a one-particle last segment
+    ("emps", 2048, {15: 1}), ("veh", 2048, {15: 1}), ("emps", 3000, {15: 1}), ("veh", 5000, {15: 1}), ("emps", 1025, {15: 1}), ("emps", 2048, {15: 1, 1: 5}), ("emps", 3000, {}),
     ("toy", 1500, {12: 16384}),       # ... one row per block
     # N <= 1024: one segment -- by default the whole sweep is one launch of one workgroup (k_sweep_small); 14: 0 = PGAS_OPT_SMALL_SWEEP off,
     # the general multi-launch path at the same sizes
@@ -113,6 +115,7 @@ def test_sweep_bit_exact(name, N, opts):
     _eq(LW, lwo, "log_weights_trace[-1]")
     _eq(traj, trajo.reshape(traj.shape), "trajectory")
     assert csmc.engine.launch_info()["small"] == (N <= 1024 and opts.get(14, 1) != 0), "which sweep ran"
+    assert csmc.engine.launch_info()["mfma"] == (opts.get(15, 0) == 1 and name in ("emps", "veh") and N > 1024), "which k_propagate ran"
     # the trajectory is a path through the trace (src/Filtering.py:40-55)
     b = csmc.engine.last_final_index()
     Xn, An = X.cpu().numpy(), ANC.cpu().numpy()
