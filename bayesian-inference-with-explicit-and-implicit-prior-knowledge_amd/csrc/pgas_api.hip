@@ -33,10 +33,13 @@
 #define PG_PPT3 8   // particles per thread of the 3-D, nx = 2 variants (EMPS / Vehicle M = 729)
 #endif
 #ifndef PG_PPT27
-#define PG_PPT27 8   // particles per thread of that variant (two segments per workgroup: the whole grid is resident at once)
+#define PG_PPT27 4   // particles per thread of that variant = one segment per workgroup
 #endif
 #ifndef PG_P27
-#define PG_P27 2   // particles per basis pass of the SingleMassOscillator-shaped FAST variant
+#define PG_P27 4   // particles per basis pass of the SingleMassOscillator-shaped FAST variant.  Round 3, interleaved A/B at N = 2^20 (ms per
+                   // sweep; the round-2 kernels had preferred PPT 8 / P 2): PPT 8 / P 2 68.1-69.4, 4 / 2 65.0, 4 / 1 70.4, 8 / 4 67.5, 8 / 8 66.9,
+                   // 4 / 4 63.0-64.9 -- one pass over the thread's four particles: every coefficient (a scalar operand) feeds four FMAs, no
+                   // next-group prefetch registers (123 VGPRs instead of 141-151: four waves per SIMD fit), 1024 workgroups
 #endif
 #ifndef PG_P3
 #define PG_P3 4   // particles per basis pass of the 3-D, nx = 2 variants: every coefficient read from LDS feeds four FMAs (measured EMPS-729 at N = 2^20: P = 1 208, P = 2 158, P = 4 147 us per step)
