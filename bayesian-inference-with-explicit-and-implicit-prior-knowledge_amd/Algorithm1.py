@@ -9,7 +9,7 @@ tensors on the GPU.  What runs where:
   needs --, the ancestor gather + forgetting + rank-one statistics update, systematic resampling, all random numbers (Philox);
 * torch (plumbing): the user's state-space model callables (StateSpaceModel), basis functions, and O(N) elementwise glue.
 
-Restrictions: scalar interface variables (n = 1, as in every instantiation of the reference); basis size M <= 62.
+Restrictions: scalar interface variables (n = 1, as in every instantiation of the reference); basis size M <= 126 (M <= 62 on the fast kernels).
 `key` is an integer seed (own Philox streams, include/pgas_canon.h) or an object with the provider interface of `DeviceRand`.
 """
 from __future__ import annotations
@@ -71,8 +71,8 @@ class Algorithm1:
             e0, e1, e2 = np.asarray(g[0], dtype=np.float64), np.asarray(g[1], dtype=np.float64), np.atleast_2d(np.asarray(g[2], dtype=np.float64))
             if e0.reshape(e1.shape[0], -1).shape[1] != 1 or self.init_int_var_mean[i].numel() != 1:
                 raise NotImplementedError("the device path handles scalar interface variables (n = 1), as every reference configuration has")
-            if e1.shape[0] > 62:
-                raise NotImplementedError("basis size M <= 62 on the device path (pgas_m_mniw_solve: M + 2 rows, one per lane)")
+            if e1.shape[0] > 126:
+                raise NotImplementedError("basis size M <= 126 on the device path (pgas_m_mniw_solve: M + 2 rows, at most two per lane)")
             self.GP_prior.append((_t(e0.reshape(-1), dev).contiguous(), _t(e1, dev).contiguous(), float(e2[0, 0]), float(g[3])))
 
     # ---------------------------------------------------------------------------------------------------------------- helpers

@@ -1303,7 +1303,7 @@ int pgas_set_option(pgas_ctx* c, int32_t option, int64_t value) {
         return PGAS_OK;
     }
     if (option == PGAS_OPT_MNIW_VALU) {
-        c->mniw_valu = value ? 1 : 0;
+        c->mniw_valu = value == 2 ? 2 : (value ? 1 : 0);   // 2: the two-rows-per-lane kernels of 63 <= M <= 126 at every M (test knob)
         return PGAS_OK;
     }
     if (option == PGAS_OPT_RESAMPLE_BEFORE_PROPAGATE) {
@@ -1851,7 +1851,7 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
                       const double* R0, const double* R1, const double* phi, double* m, double* cc, double* q, double* logdet, double* Lfac, void* sh) {
     if (!c) return PGAS_E_ARG;
     if (!P0 || !P1 || !T0 || !T1 || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: NULL argument");
-    if (M < 1 || M > PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: M = %d outside [1, %d]", M, PG_MN_MAXM);
+    if (M < 1 || M > PG_MN_MAXM_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: M = %d outside [1, %d]", M, PG_MN_MAXM_WIDE);
     if ((R0 == nullptr) != (R1 == nullptr)) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: R0 and R1 must be given together");
     if (n == 0) return PGAS_OK;
     DeviceGuard guard(c->device);
@@ -1860,7 +1860,12 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
         HIPCHK(c, hipMalloc(&c->d_fail, sizeof(int32_t)));
         HIPCHK(c, hipMemsetAsync(c->d_fail, 0, sizeof(int32_t), st));
     }
-    if (c->mniw_valu) {
+    if (M > PG_MN_MAXM || c->mniw_valu == 2) {
+        // 63 ... 126 basis functions (or the test knob): two rows per lane, the triangle in LDS
+        const size_t lds = (size_t)((M + 2) * (M + 3) / 2) * sizeof(double);
+        if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)k_mniw_solve_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mniw_solve_wide, dim3((unsigned)n), dim3(64), lds, st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q, logdet, Lfac, c->d_fail);
+    } else if (c->mniw_valu) {
         const int MT = M <= 22 ? 24 : M <= 30 ? 32 : M <= 42 ? 44 : M <= 46 ? 48 : 64;   // rows: M + 2 (the right-hand sides ride along)
         const int waves = MT == 64 ? 2 : 4;   // LDS: waves x MT (MT+1)/2 doubles <= 64 KB
         const dim3 grd((unsigned)((n + waves - 1) / waves)), blk(64 * waves);
@@ -1884,9 +1889,16 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
 int pgas_m_mniw_trisolve(pgas_ctx* c, int64_t n, int32_t M, const int32_t* anc, const double* Lfac, const double* phi, double* m, double* cc, void* sh) {
     if (!c) return PGAS_E_ARG;
     if (!Lfac || !phi || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: NULL argument");
-    if (M < 1 || M > PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: M = %d outside [1, %d]", M, PG_MN_MAXM);
+    if (M < 1 || M > PG_MN_MAXM_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: M = %d outside [1, %d]", M, PG_MN_MAXM_WIDE);
     if (n == 0) return PGAS_OK;
     DeviceGuard guard(c->device);
+    if (M > PG_MN_MAXM || c->mniw_valu == 2) {
+        const size_t lds = (size_t)((M + 2) * (M + 3) / 2) * sizeof(double);
+        if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)k_mniw_trisolve_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_mniw_trisolve_wide, dim3((unsigned)n), dim3(64), lds, (hipStream_t)sh, n, M, anc, Lfac, phi, m, cc);
+        KCHK(c, "k_mniw_trisolve_wide");
+        return PGAS_OK;
+    }
     const int waves = 4;
     hipLaunchKernelGGL(k_mniw_trisolve, dim3((unsigned)((n + waves - 1) / waves)), dim3(64 * waves),
                        (size_t)waves * ((M + 2) * (M + 3) / 2) * sizeof(double), (hipStream_t)sh, n, M, anc, Lfac, phi, m, cc);
@@ -1913,7 +1925,7 @@ int pgas_m_stats_gather_update(pgas_ctx* c, int64_t n, int32_t M, double scale, 
     if (!c) return PGAS_E_ARG;
     if (!T0i || !T1i || !T2i || !T3i || !phi || !xi || !T0o || !T1o || !T2o || !T3o || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: NULL argument");
     if (T0i == T0o || T1i == T1o || T2i == T2o || T3i == T3o) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: input and output alias");
-    if (M < 1 || M > 2 * PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: M = %d outside [1, %d]", M, 2 * PG_MN_MAXM);
+    if (M < 1 || M > PG_MN_MAXM_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: M = %d outside [1, %d]", M, PG_MN_MAXM_WIDE);
     if (n == 0) return PGAS_OK;
     DeviceGuard guard(c->device);
     hipLaunchKernelGGL(k_stats_gather_update, dim3((unsigned)n), dim3(256), 0, (hipStream_t)sh, n, M, scale, anc, T0i, T1i, T2i, T3i, phi, xi, T0o, T1o, T2o, T3o);
@@ -1925,7 +1937,7 @@ int pgas_m_weighted_stats(pgas_ctx* c, int64_t n, int32_t M, const double* w, co
                           double* S0, double* S1, double* S2, double* S3, void* sh) {
     if (!c) return PGAS_E_ARG;
     if (!w || !T0 || !T1 || !T2 || !T3 || !S0 || !S1 || !S2 || !S3 || n < 1) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: bad argument");
-    if (M < 1 || M > 2 * PG_MN_MAXM) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: M = %d outside [1, %d]", M, 2 * PG_MN_MAXM);
+    if (M < 1 || M > PG_MN_MAXM_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: M = %d outside [1, %d]", M, PG_MN_MAXM_WIDE);
     DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)sh;
     const int ncol = M * M + M + 2;

@@ -368,6 +368,129 @@ __global__ __launch_bounds__(256) void k_mniw_trisolve(int64_t n, int M, const i
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Bases of 63 ... 126 functions (the reference's formulas, BI:48-50,64-124, are general in M): M + 2 rows no longer fit one per lane.
+// k_mniw_solve_wide / k_mniw_trisolve_wide: one wave per particle, TWO rows per lane (rows lane and lane + 64), the packed triangle
+// in LDS (66 KB at M = 126) and updated in place, column by column -- the SAME operations in the same order as k_mniw_solve (pivot
+// 1 / sqrt by v_rsq_f64 + two Newton steps, A[r][j] = fma(-L[r][k], L[j][k], A[r][j]) for k ascending, right-hand sides as two extra
+// rows), so that for M <= 62 the results are bit-identical to it (tests/test_gpu_marginal.py).  A generality path, not a fast one:
+// every FMA costs two LDS reads and a write.
+// ------------------------------------------------------------------------------------------
+#define PG_MN_MAXM_WIDE 126
+__global__ __launch_bounds__(64) void k_mniw_solve_wide(int64_t n, int M, double scale, const int32_t* __restrict__ anc, const double* __restrict__ P0,
+                                                         const double* __restrict__ P1, const double* __restrict__ T0,
+                                                         const double* __restrict__ T1, const double* __restrict__ R0,
+                                                         const double* __restrict__ R1, const double* __restrict__ phi,
+                                                         double* __restrict__ m_out, double* __restrict__ c_out,
+                                                         double* __restrict__ q_out, double* __restrict__ logdet_out,
+                                                         double* __restrict__ Lfac_out, int32_t* __restrict__ fail_out) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int64_t p = blockIdx.x;
+    if (p >= n) return;
+    const int64_t src = anc ? (int64_t)anc[p] : p;
+    double* __restrict__ A = smem;
+    const double* __restrict__ T1p = T1 + (size_t)src * M * M;
+    const int R = M + 2;
+    for (int r = 0; r < M; ++r)
+        for (int j = lane; j <= r; j += 64) {
+            double v = P1[r * M + j] + scale * T1p[r * M + j];
+            if (R1) v += R1[r * M + j];
+            A[r * (r + 1) / 2 + j] = v;
+        }
+    const int tM = M * (M + 1) / 2, tM1 = (M + 1) * (M + 2) / 2;   // starts of rows M and M+1
+    for (int j = lane; j < M; j += 64) {
+        double w = P0[j] + scale * T0[(size_t)src * M + j];
+        if (R0) w += R0[j];
+        A[tM + j] = phi ? phi[(size_t)p * M + j] : 0.0;
+        A[tM1 + j] = w;
+    }
+    if (lane == 0) {   // the corner: (M,M), (M+1,M), (M+1,M+1)
+        A[tM + M] = 0.0;
+        A[tM1 + M] = 0.0;
+        A[tM1 + M + 1] = 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int r0 = lane, r1 = lane + 64;
+    const int t0 = r0 * (r0 + 1) / 2, t1 = r1 * (r1 + 1) / 2;
+    for (int k = 0; k < M; ++k) {
+        const int tk = k * (k + 1) / 2;
+        const double inv = rsqrt_newton(A[tk + k]);
+        double l0 = 0.0, l1 = 0.0;
+        if (r0 > k && r0 < R) l0 = A[t0 + k] * inv;
+        if (r1 > k && r1 < R) l1 = A[t1 + k] * inv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (r0 > k && r0 < R) A[t0 + k] = l0;
+        if (r1 > k && r1 < R) A[t1 + k] = l1;
+        if (r0 == k) A[t0 + k] = inv;        // 1 / L_kk on the diagonal, the packed format of k_mniw_solve
+        if (r1 == k) A[t1 + k] = inv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (r0 > k && r0 < R) {
+            const double nl = -l0;
+            for (int j = k + 1; j <= r0; ++j) A[t0 + j] = PGAS_FMA(nl, A[j * (j + 1) / 2 + k], A[t0 + j]);
+        }
+        if (r1 > k && r1 < R) {
+            const double nl = -l1;
+            for (int j = k + 1; j <= r1; ++j) A[t1 + j] = PGAS_FMA(nl, A[j * (j + 1) / 2 + k], A[t1 + j]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (Lfac_out) {
+        const int tri_out = (M + 2) * (M + 3) / 2;
+        double* __restrict__ dst = Lfac_out + (size_t)p * tri_out;
+        for (int e = lane; e < tri_out; e += 64) dst[e] = A[e];
+    }
+    const double d0 = r0 < M ? A[t0 + r0] : 1.0, d1 = r1 < M ? A[t1 + r1] : 1.0;
+    const double ld = -2.0 * wave_sum_f64((r0 < M ? pgas_log(d0) : 0.0) + (r1 < M ? pgas_log(d1) : 0.0));
+    if (lane == 0) {
+        if (c_out) c_out[p] = -A[tM + M];
+        if (m_out) m_out[p] = -A[tM1 + M];
+        if (q_out) q_out[p] = -A[tM1 + M + 1];
+        if (logdet_out) logdet_out[p] = ld;
+        if (!(ld - ld == 0.0) && fail_out) atomicAdd(fail_out, 1);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_mniw_trisolve_wide(int64_t n, int M, const int32_t* __restrict__ anc, const double* __restrict__ Lfac,
+                                                            const double* __restrict__ phi, double* __restrict__ m_out, double* __restrict__ c_out) {
+    extern __shared__ double smem[];
+    const int lane = threadIdx.x;
+    const int64_t p = blockIdx.x;
+    if (p >= n) return;
+    const int64_t src = anc ? (int64_t)anc[p] : p;
+    const int tri_n = (M + 2) * (M + 3) / 2;
+    double* __restrict__ A = smem;
+    const double* __restrict__ Ls = Lfac + (size_t)src * tri_n;
+    for (int e = lane; e < tri_n; e += 64) A[e] = Ls[e];
+    const int r0 = lane, r1 = lane + 64;
+    double b0 = r0 < M ? phi[(size_t)p * M + r0] : 0.0, b1 = r1 < M ? phi[(size_t)p * M + r1] : 0.0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int t0 = r0 < M ? r0 * (r0 + 1) / 2 : 0, t1 = r1 < M ? r1 * (r1 + 1) / 2 : 0;
+    const int tw = (M + 1) * (M + 2) / 2;
+    const double w0 = r0 < M ? A[tw + r0] : 0.0, w1 = r1 < M ? A[tw + r1] : 0.0;
+    const double di0 = r0 < M ? A[t0 + r0] : 1.0, di1 = r1 < M ? A[t1 + r1] : 1.0;
+    for (int k = 0; k < M; ++k) {
+        const int kl = k & 63;
+        const double bk = k < 64 ? readlane_f64(b0, kl) * readlane_f64(di0, kl) : readlane_f64(b1, kl) * readlane_f64(di1, kl);   // uniform
+        const double lk0 = (r0 > k && r0 < M) ? A[t0 + k] : 0.0, lk1 = (r1 > k && r1 < M) ? A[t1 + k] : 0.0;
+        if (r0 == k) b0 = bk;
+        else if (r0 > k) b0 = PGAS_FMA(-lk0, bk, b0);
+        if (r1 == k) b1 = bk;
+        else if (r1 > k) b1 = PGAS_FMA(-lk1, bk, b1);
+    }
+    const double mm = wave_sum_f64((r0 < M ? w0 * b0 : 0.0) + (r1 < M ? w1 * b1 : 0.0));
+    const double cc = wave_sum_f64((r0 < M ? b0 * b0 : 0.0) + (r1 < M ? b1 * b1 : 0.0));
+    if (lane == 0) {
+        if (m_out) m_out[p] = mm;
+        if (c_out) c_out[p] = cc;
+    }
+}
+
 // one workgroup per particle: T_out[p] = scale * T_in[a_p] + update
 __global__ __launch_bounds__(256) void k_stats_gather_update(int64_t n, int M, double scale, const int32_t* __restrict__ anc,
                                                               const double* __restrict__ T0i, const double* __restrict__ T1i,

@@ -174,7 +174,7 @@ int pgas_get_launch_info(pgas_ctx* ctx, int32_t* info4);
 #define PGAS_OPT_MFMA_PROPAGATE 15 /* 1: models with a 3-D basis, n_x = 2 and the 729-function index ball of the 11 x 11 x 11 grid (EMPS / Vehicle, src/EMPS.py:101-113) run the innermost sum of k_propagate's contraction A phi(x) (src/PGAS.py:52-55) on v_mfma_f64_16x16x4_f64, whose four-term accumulation is the canonical ascending fma chain: bit-identical to the vector-ALU form.  Default 0: on MI355X the f64 MFMA occupies the SIMD's vector pipeline (no overlap with vector fp64 work, tools/probes/mfma_valu_overlap_probe.hip) and the padded tiles carry 1.5x the flops: 126 against 114 us per step */
 #define PGAS_OPT_GRAPH 13 /* 1: pgas_sweep captures its launches (k_init ... k_backtrace, both streams) once in a HIP graph and replays it per sweep on an internal stream -- seed, uniforms, transition parameters, reference trajectory and result all live in device memory the graph's kernels read at execution time; same kernels, same order: identical results.  0: enqueue every launch (what profiled sweeps, the corrected mode and sharded sweeps always do).  Default: off -- on the HIP 7.0 runtime bundled with PyTorch 2.10 the replay measured slower than enqueueing at every size */
 #define PGAS_OPT_TRACE_BLOCK_BYTES 12 /* before the first sweep / pgas_shard_setup: keep the traces in row blocks of at most this many bytes (0 = default: one array per trace on an unsharded context, 1 GiB blocks on a shard); small values are a test knob that puts block boundaries inside short sweeps */
-#define PGAS_OPT_MNIW_VALU 6 /* 1: pgas_m_mniw_solve factorises column by column on the VALU instead of in MFMA-blocked panels (test knob) */
+#define PGAS_OPT_MNIW_VALU 6 /* 1: pgas_m_mniw_solve factorises column by column on the VALU instead of in MFMA-blocked panels; 2: the two-rows-per-lane kernels of 63 <= M <= 126 at every M (test knobs) */
 int pgas_set_option(pgas_ctx* ctx, int32_t option, int64_t value);
 
 /* Free functions of src/Filtering.py on the device.  systematic_SISR(key, w) (:6-37): u = the uniform the reference draws

@@ -47,7 +47,8 @@ int pgas_m_rng_chi2(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t, i
                     void* stream_handle);
 
 /* Per particle p, with s = anc[p] (anc NULL: s = p): eta0 = P0 + scale T0[s] (+ R0), eta1 = P1 + scale T1[s] (+ R1)
- * (M <= 62, eta1 symmetric positive definite);
+ * (M <= 126, eta1 symmetric positive definite; M <= 62: one matrix row per lane, the trailing update on the f64 matrix cores; 63 ... 126: two rows
+ * per lane, the triangle updated in place in LDS -- a generality path);
  *   m[p] = eta0^T eta1^-1 phi[p],  c[p] = phi[p]^T eta1^-1 phi[p],  q[p] = eta0^T eta1^-1 eta0,  logdet[p] = log det eta1.
  * R0/R1 (the reference trajectory's statistics, src/Algorithm3.py:96-101), phi and every output may be NULL.
  * Lfac_dev (n, (M+2)(M+3)/2), optional, receives the packed Cholesky factor for pgas_m_mniw_trisolve: rows of L with 1/L_kk on the

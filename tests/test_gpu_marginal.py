@@ -35,6 +35,45 @@ def test_rng_kernels_bit_exact():
     assert ops.uniform(SEED, 18, 7) == canon.uniform(SEED, 18, 7)
 
 
+@pytest.mark.parametrize("N,M", [(130, 63), (70, 64), (90, 100), (257, 126), (64, 127)])
+def test_mniw_solve_wide_bases(N, M):
+    """63 <= M <= 126 (the reference's formulas, BI:48-50,64-124, are general in M): the two-rows-per-lane kernels; M = 127 is a clean error."""
+    ops = _ops(N)
+    if M > 126:
+        z = torch.zeros(N, M, dtype=torch.float64, device=ops.device)
+        from pgas_amd._lib import PgasError
+        with pytest.raises(PgasError, match="outside"):
+            ops.mniw_solve(z[0], torch.eye(M, dtype=torch.float64, device=ops.device), z, torch.zeros(N, M, M, dtype=torch.float64, device=ops.device), phi=z)
+        return
+    _check_mniw_solve(ops, N, M)
+
+
+@pytest.mark.parametrize("N,M", [(300, 41), (257, 62), (70, 14), (64, 1)])
+def test_mniw_wide_kernels_match_the_row_per_lane_kernel_bit_for_bit(N, M):
+    """PGAS_OPT_MNIW_VALU = 2 runs the wide kernels at any M: same operations in the same order as the column-by-column kernel (= 1)."""
+    ops = _ops(N)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    dev = ops.device
+    B = torch.randn(N, M, 3, generator=g, dtype=torch.float64)
+    T1 = (B @ B.transpose(1, 2)).to(dev).contiguous()
+    T0 = torch.randn(N, M, generator=g, dtype=torch.float64).to(dev)
+    P1 = torch.diag(torch.rand(M, generator=g, dtype=torch.float64) + 0.5).to(dev)
+    P0 = torch.randn(M, generator=g, dtype=torch.float64).to(dev)
+    phi = torch.randn(N, M, generator=g, dtype=torch.float64).to(dev)
+    anc = torch.randint(0, N, (N,), generator=g).to(dev).to(torch.int32)
+    out = {}
+    try:
+        for knob in (1, 2):
+            ops.eng.set_option(6, knob)
+            full = ops.mniw_solve(P0, P1, T0, T1, scale=0.999, anc=anc, phi=phi, keep_factor=True)
+            tri = ops.mniw_trisolve(full, anc, phi)
+            out[knob] = {k: full[k].clone() for k in ("m", "c", "q", "logdet")} | {"tm": tri["m"].clone(), "tc": tri["c"].clone()}
+    finally:
+        ops.eng.set_option(6, 0)
+    for k in out[1]:
+        assert torch.equal(out[1][k], out[2][k]), k
+
+
 @pytest.mark.parametrize("valu", [0, 1])
 @pytest.mark.parametrize("N,M", [(300, 41), (1000, 20), (257, 62), (500, 46), (300, 30), (70, 14), (64, 1), (130, 5)])
 def test_mniw_solve_against_torch(N, M, valu):
@@ -161,6 +200,24 @@ def test_algorithm1_matches_restatement(name, N):
     assert got[2][0][0].shape == (pb.T, pb.GP_prior[0][0].shape[0], 1) and got[5][0][2].shape == (N, 1, 1)   # the reference's shapes
 
 
+def test_marginalised_filter_with_a_wide_basis():
+    """M = 80 basis functions per latent function (the reference runs Vehicle with 20): the filter steps go through the
+    two-rows-per-lane MNIW kernels and still match the NumPy restatement.  (Algorithm1 only: the literal restatement of the
+    conditional filter's base measures takes log(det eta1) as the reference does, BI:119, which overflows at this size -- the
+    device works with log det throughout.)"""
+    N = 100
+    pb = experiments.vehicle_marginal(T=6, M=80)
+    ref = marginal_oracle(pb, N)(CanonRand(SEED, N))
+    got = _device_alg(pb, N)(SEED)
+    assert np.array_equal(got[4].cpu().numpy(), ref[4]), "ancestor_trace"
+    _close(got[0], ref[0], "state_trace")
+    for i in range(len(pb.basis)):
+        _close(got[1][i], ref[1][i], f"int_var_trace[{i}]")
+        for j in range(4):
+            _close(got[5][i][j], ref[5][i][j], f"suff_stats[{i}][{j}]")
+    _close(got[3], ref[3], "weights_trace")
+
+
 def _flat(out):
     st, iv, sst, w, anc, stats, obs, ll = out
     return [st, w, anc, obs, ll] + list(iv) + [t for s in sst for t in s] + [t for s in stats for t in s]
@@ -179,7 +236,10 @@ def test_algorithm1_graph_replay_equals_eager_loop(name):
 
 @pytest.mark.parametrize("name,N", [("smo", 150), ("toy", 150), ("vehicle", 200)])
 def test_algorithm3_matches_restatement(name, N):
-    pb = _problem(name)
+    _algorithm3_case(_problem(name), N)
+
+
+def _algorithm3_case(pb, N):
     oracle = marginal_oracle(pb, N, "Algorithm3")
     ref_x, ref_iv = pb.X_true, list(pb.int_var_true)
     ref_stats = mo.trajectory_stats(oracle, ref_x, ref_iv)
