@@ -553,9 +553,10 @@ def main():
                 "sweep_note": "sweep_* = 52 B x N x (T-1) / wall of the whole sweep per GPU: both kernels, launch gaps, final draw and back-trace included",
                 "hbm_copy_GBs": hbm_copy_rate(torch, eng.device),   # measured attainable rate of a 1 GiB device copy, outside the timed region
                 "second_kernel": oth,
-                "note": "the two kernels run concurrently on two streams and share the vector ALUs; together they issue ~850 fp64-rate vector instructions per "
-                        "particle-step, which bounds a step at ~26 us against 6.8 us of HBM time: DESIGN.md section 5, profiles/r03_pmc_sq_*.txt -- the HBM fraction "
-                        "says little about either kernel",
+                "note": "the two kernels run concurrently on two streams; the period of a step is the weight recursion's dependent chain (k_step + k_groups + "
+                        "two launch boundaries), with k_propagate hidden under it.  Together they issue ~850 vector instructions per particle-step (~26 us per "
+                        "step at the nominal 4 cycles each, ~31 us at the 5.5 a stream of independent v_fma_f64 really reaches: "
+                        "profiles/r03_probe_valu_f64_rate.txt) and move 114 MB of real traffic per step against 54.5 MB algorithmic: DESIGN.md sections 5 and 8",
             }
         if args.cpu_steps > 0 and world == 1:
             Ah, Sh = A.cpu().numpy(), S.cpu().numpy()
