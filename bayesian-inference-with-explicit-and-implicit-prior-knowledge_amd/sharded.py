@@ -218,5 +218,7 @@ def make_dist_group(N_global, observations, inputs, init_state_mean, init_state_
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     Nl = shard_layout(N_global, world)
-    shard = _Shard(_shard_engine(Nl, (observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn), device, trace_block_bytes), rank, world)
-    return DistGroup(shard, group)
+    made = []   # the engine (device tables, scan buffers) is created inside an agreed step too: a rank that cannot allocate takes the others down with a message
+    agree_on(dist, group, "create this rank's engine", lambda: made.append(
+        _Shard(_shard_engine(Nl, (observations, inputs, init_state_mean, init_state_cov, likelihood_fcn, basis_fcn), device, trace_block_bytes), rank, world)))
+    return DistGroup(made[0], group)

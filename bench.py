@@ -388,9 +388,8 @@ def main():
         try:
             grp = sharded.make_dist_group(N * world, pb.observations, pb.inputs, pb.init_state_mean, pb.init_state_cov, pb.likelihood_fcn,
                                           pb.basis_fcn, device=f"cuda:{local_rank}")
-        except sharded.PgasError as e:   # raised on EVERY rank when any rank failed (IPC mapping, RCCL communicator)
-            if rank == 0:
-                print(f"bench.py: setup of the particle-sharded sweep failed: {e}", file=sys.stderr, flush=True)
+        except sharded.PgasError as e:   # raised on EVERY rank when any rank failed (allocation, IPC mapping, RCCL communicator)
+            print(f"bench.py [rank {rank}]: setup of the particle-sharded sweep failed: {e}", file=sys.stderr, flush=True)
             raise SystemExit(3)
         eng = grp.shards[0].eng
     else:
