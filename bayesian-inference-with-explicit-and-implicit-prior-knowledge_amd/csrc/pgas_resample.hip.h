@@ -20,7 +20,9 @@
 #define PG_WIN_SEG 1024                      // segments a workgroup keeps in LDS (its search window)
 #define PG_WIN_GRP (PG_WIN_SEG / PG_GRP)
 #define PG_LOCAL_NSEG PG_WIN_SEG             // k_step<true>: the window is the whole device
+#ifndef PG_FSTAGE
 #define PG_FSTAGE 2                          // source segments staged at once (LDS budget: five workgroups per CU)
+#endif
 #define PG_NCAND 8                           // staged candidates per workgroup before falling back to per-slot bisection
 #define PG_DEXP_ZERO (-32768)
 #ifdef PG_COLD_NOINLINE
@@ -495,7 +497,7 @@ __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOC
         __syncthreads();
         for (int k0w = 0; k0w < ns; k0w += PG_FSTAGE) {  // uniform
             const int ng = ns - k0w < PG_FSTAGE ? ns - k0w : PG_FSTAGE;
-            int sb_idx[PG_FSTAGE] = {0, 0};
+            int sb_idx[PG_FSTAGE] = {};
             SegParams sp[PG_FSTAGE];
 #pragma unroll
             for (int g = 0; g < PG_FSTAGE; ++g)
@@ -543,7 +545,10 @@ __device__ __forceinline__ void resample_search(const DevModel& md, WinSmemT<LOC
             for (int j = 0; j < PG_PPT; ++j) {
                 if (g_carry < tau[j] && pos[j] < ng * PGAS_SEG) {
                     const int g = pos[j] >> 10, off = pos[j] & (PGAS_SEG - 1);
-                    const int64_t ai = (int64_t)(g == 0 ? sb_idx[0] : sb_idx[1]) * PGAS_SEG + off;
+                    int sbg = sb_idx[0];
+#pragma unroll
+                    for (int q = 1; q < PG_FSTAGE; ++q) sbg = g == q ? sb_idx[q] : sbg;
+                    const int64_t ai = (int64_t)sbg * PGAS_SEG + off;
                     a[j] = ai > N - 1 ? N - 1 : (int)ai;
                 }
             }
