@@ -351,7 +351,7 @@ def test_error_reporting():
 
 @pytest.mark.parametrize("name,N,world,blk", [("smo", 4096, 2, None), ("smo", 8192, 4, 1 << 17), ("smo", 65536, 8, None), ("toy", 2048, 2, 8192), ("emps", 2048, 2, None),
                                                ("veh27", 4096, 2, 1 << 16),
-                                               ("emps", 8192, 8, None), ("veh", 8192, 8, 1 << 18)])   # BASELINE configs[4]'s 8-way placement (M = 729), small N
+                                               ("emps", 8192, 8, None), ("veh", 8192, 8, 1 << 16)])   # BASELINE configs[4]'s 8-way placement (M = 729), small N
 def test_sharded_sweep_bit_exact_and_independent_of_world(name, N, world, blk):
     """Particle-sharded sweep (several shards emulated in one process on one device): the trajectory and the traces are the
     single-device / oracle ones bit for bit, whatever the number of shards."""
