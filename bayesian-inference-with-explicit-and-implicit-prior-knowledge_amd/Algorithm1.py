@@ -9,7 +9,9 @@ tensors on the GPU.  What runs where:
   needs --, the ancestor gather + forgetting + rank-one statistics update, systematic resampling, all random numbers (Philox);
 * torch (plumbing): the user's state-space model callables (StateSpaceModel), basis functions, and O(N) elementwise glue.
 
-Restrictions: scalar interface variables (n = 1, as in every instantiation of the reference); basis size M <= 126 (M <= 62 on the fast kernels).
+Limits: M + 1 + n <= 128 per latent function (basis size M, n components of its interface variable; n <= 8).  n = 1 with M <= 62 -- every
+instantiation of the reference -- runs on the fast kernels; wider bases and n > 1 (the reference's formulas, BI:18-108, are general in n) on
+the two-rows-per-lane generality kernels.  Algorithm3 (conditional filter) takes n = 1 only.
 `key` is an integer seed (own Philox streams, include/pgas_canon.h) or an object with the provider interface of `DeviceRand`.
 """
 from __future__ import annotations
@@ -45,6 +47,20 @@ class DeviceRand:
         return self.ops.student_t(self.seed, stream, t, nu)
 
 
+def _small_cholesky(A):
+    """Lower Cholesky factors of a batch (N, n, n) of small matrices in elementwise torch operations: no library call, no workspace, no
+    host synchronisation -- the filter step that contains it can be captured in a HIP graph (torch.linalg.cholesky cannot)."""
+    n = A.shape[-1]
+    L = torch.zeros_like(A)
+    for j in range(n):
+        for i in range(j, n):
+            s = A[:, i, j]
+            for k in range(j):
+                s = s - L[:, i, k] * L[:, j, k]
+            L[:, i, j] = torch.sqrt(s) if i == j else s / L[:, j, j]
+    return L
+
+
 def _t(a, dev):
     return torch.as_tensor(np.asarray(a, dtype=np.float64), device=dev)
 
@@ -66,14 +82,20 @@ class Algorithm1:
         self.basis_fcn = list(basis_fcn)
         self.N_int = len(self.basis_fcn)
         self.dim_basis = [int(self.basis_fcn[i](self.init_state_mean.reshape(1, -1), self.inputs[0]).shape[-1]) for i in range(self.N_int)]  # :56-62
-        self.GP_prior = []
+        self.GP_prior, self.nvar = [], []
         for i, g in enumerate(GP_prior):
             e0, e1, e2 = np.asarray(g[0], dtype=np.float64), np.asarray(g[1], dtype=np.float64), np.atleast_2d(np.asarray(g[2], dtype=np.float64))
-            if e0.reshape(e1.shape[0], -1).shape[1] != 1 or self.init_int_var_mean[i].numel() != 1:
-                raise NotImplementedError("the device path handles scalar interface variables (n = 1), as every reference configuration has")
-            if e1.shape[0] > 126:
-                raise NotImplementedError("basis size M <= 126 on the device path (pgas_m_mniw_solve: M + 2 rows, at most two per lane)")
-            self.GP_prior.append((_t(e0.reshape(-1), dev).contiguous(), _t(e1, dev).contiguous(), float(e2[0, 0]), float(g[3])))
+            M = e1.shape[0]
+            nv = e0.reshape(M, -1).shape[1]
+            if self.init_int_var_mean[i].numel() != nv or e2.shape != (nv, nv):
+                raise ValueError(f"interface variable {i}: eta0 is (M, {nv}) but init_int_var_mean / eta2 have other sizes")
+            if nv > 8 or M + 1 + nv > 128:
+                raise NotImplementedError("M + 1 + n <= 128 and n <= 8 on the device path (pgas_m_mniw_solve_n: at most two matrix rows per lane)")
+            self.nvar.append(nv)
+            if nv == 1:   # the scalar layout of the fast kernels: eta0 (M,), eta2 a float
+                self.GP_prior.append((_t(e0.reshape(-1), dev).contiguous(), _t(e1, dev).contiguous(), float(e2[0, 0]), float(g[3])))
+            else:
+                self.GP_prior.append((_t(e0.reshape(M, nv), dev).contiguous(), _t(e1, dev).contiguous(), _t(e2, dev).contiguous(), float(g[3])))
 
     # ---------------------------------------------------------------------------------------------------------------- helpers
     _tidx = None   # graph mode: (t, t - 1) as one-element int64 device tensors; rows are then gathered on the device
@@ -90,14 +112,20 @@ class Algorithm1:
     def _rand(self, key):
         return key if hasattr(key, "student_t") else DeviceRand(self.ops, prng.as_key(key))
 
-    @staticmethod
-    def _ref_shapes(stats):
-        """(T0 (N,M), T1 (N,M,M), T2 (N,), T3 (N,)) -> the reference's shapes (N,M,1), (N,M,M), (N,1,1), (N,)."""
-        return tuple((s[0].unsqueeze(-1), s[1], s[2].reshape(-1, 1, 1), s[3]) for s in stats)
+    def _ref_shapes(self, stats):
+        """(T0 (N,M), T1 (N,M,M), T2 (N,), T3 (N,)) -> the reference's shapes (N,M,n), (N,M,M), (N,n,n), (N,)."""
+        return tuple((s[0].reshape(s[0].shape[0], s[0].shape[1], nv), s[1], s[2].reshape(-1, nv, nv), s[3]) for s, nv in zip(stats, self.nvar))
 
-    @staticmethod
-    def _dev_shapes(stats):
-        return tuple((s[0].reshape(s[0].shape[0], -1).contiguous(), s[1].contiguous(), s[2].reshape(-1).contiguous(), s[3].reshape(-1).contiguous()) for s in stats)
+    def _dev_shapes(self, stats):
+        """n = 1: the unit axes dropped (T0 (N,M), T2 (N,)); n > 1: the reference's own shapes."""
+        out = []
+        for s, nv in zip(stats, self.nvar):
+            N = s[0].shape[0]
+            if nv == 1:
+                out.append((s[0].reshape(N, -1).contiguous(), s[1].contiguous(), s[2].reshape(-1).contiguous(), s[3].reshape(-1).contiguous()))
+            else:
+                out.append((s[0].reshape(N, -1, nv).contiguous(), s[1].contiguous(), s[2].reshape(N, nv, nv).contiguous(), s[3].reshape(-1).contiguous()))
+        return tuple(out)
 
     def _weighted(self, stats, w):
         """sum_n w_n T_n for the statistics trace (src/Algorithm1.py:166-170, :445-457)."""
@@ -107,8 +135,8 @@ class Algorithm1:
     def _init_trace_vars(self):
         T, N, dev = self.observations.shape[0], self.N_samples, self.device
         z = lambda *s: torch.zeros(s, dtype=torch.float64, device=dev)  # noqa: E731
-        return (z(T, N, self.init_state_mean.numel()), [z(T, N, 1) for _ in range(self.N_int)],
-                [[z(T, M, 1), z(T, M, M), z(T, 1, 1), z(T)] for M in self.dim_basis], z(T, N),
+        return (z(T, N, self.init_state_mean.numel()), [z(T, N, nv) for nv in self.nvar],
+                [[z(T, M, nv), z(T, M, M), z(T, nv, nv), z(T)] for M, nv in zip(self.dim_basis, self.nvar)], z(T, N),
                 torch.zeros((T - 1, N), dtype=torch.int32, device=dev))
 
     def _init_algorithm(self, rand):
@@ -119,11 +147,18 @@ class Algorithm1:
         suff_stats = []
         w = torch.full((N,), 1.0 / N, dtype=torch.float64, device=dev)                     # softmax of zeros, :166
         for i in range(self.N_int):
-            sd = float(np.sqrt(self.init_int_var_cov[i][0, 0]))
-            int_var_trace[i][0] = self.init_int_var_mean[i] + sd * rand.normal(STREAM_INIT_INTVAR + i, 0, 1)      # :146-153
+            nv = self.nvar[i]
             basis = self.basis_fcn[i](state_trace[0], self.inputs[0]).contiguous()         # :158-160
-            xi = int_var_trace[i][0].reshape(-1)
-            Ts = ((basis * xi[:, None]).contiguous(), (basis[:, :, None] * basis[:, None, :]).contiguous(), xi * xi, torch.ones_like(xi))   # :161-163
+            if nv == 1:
+                sd = float(np.sqrt(self.init_int_var_cov[i][0, 0]))
+                int_var_trace[i][0] = self.init_int_var_mean[i] + sd * rand.normal(STREAM_INIT_INTVAR + i, 0, 1)      # :146-153
+                xi = int_var_trace[i][0].reshape(-1)
+                Ts = ((basis * xi[:, None]).contiguous(), (basis[:, :, None] * basis[:, None, :]).contiguous(), xi * xi, torch.ones_like(xi))   # :161-163
+            else:
+                int_var_trace[i][0] = self.init_int_var_mean[i] + rand.normal(STREAM_INIT_INTVAR + i, 0, nv) @ _t(np.linalg.cholesky(self.init_int_var_cov[i]), dev).T
+                xi = int_var_trace[i][0]
+                Ts = ((basis[:, :, None] * xi[:, None, :]).contiguous(), (basis[:, :, None] * basis[:, None, :]).contiguous(),
+                      (xi[:, :, None] * xi[:, None, :]).contiguous(), torch.ones(N, dtype=torch.float64, device=dev))
             suff_stats.append(Ts)
             for j, v in enumerate(self._weighted(Ts, w)):
                 sst[i][j][0] = v.reshape(sst[i][j][0].shape)                               # :167-170
@@ -141,7 +176,7 @@ class Algorithm1:
             P0, P1, _, _ = self.GP_prior[i]
             # mean_i phi = eta0^T eta1^-1 phi (BI:48-50, :228-231); `scale` carries the forgetting factor of :317-320
             sol = self.ops.mniw_solve(P0, P1, suff_stats[i][0], suff_stats[i][1], scale=scale, phi=basis, want=("m", "q", "logdet"), keep_factor=True)
-            aux_int_var.append(sol["m"].unsqueeze(-1))
+            aux_int_var.append(sol["m"].unsqueeze(-1) if self.nvar[i] == 1 else sol["m"])   # (N, n)
             factors.append(sol)
         return aux_state, tuple(aux_int_var), factors
 
@@ -156,6 +191,16 @@ class Algorithm1:
             _, _, P2, P3 = self.GP_prior[i]
             _, _, T2, T3 = suff_stats[i]
             sol = self.ops.mniw_trisolve(factors[i], a, basis)                             # m = mean phi (BI:81), c = phi^T col_cov phi (BI:84)
+            if self.nvar[i] > 1:
+                nv = self.nvar[i]
+                df = P3 + scale * T3[ai] + 1.0 - nv                                        # BI:45, :78
+                row = (P2 + scale * T2[ai] - factors[i]["q"][ai]) / df[:, None, None]       # BI:42, :87 -- (N, n, n)
+                Lr = _small_cholesky(row)                                                  # BI:100
+                t = torch.stack([rand.student_t(STREAM_INTVAR + i + 16 * j, time, df) for j in range(nv)], dim=1)   # BI:104: n variates per particle
+                draw = sol["m"] + torch.einsum("nij,nj->ni", Lr, t) * torch.sqrt(sol["c"] + 1.0)[:, None]           # BI:106-108 (col_scale is 1 x 1)
+                int_var.append(draw)
+                basis_all.append(basis)
+                continue
             df = P3 + scale * T3[ai]                                                       # BI:45; BI:78 with n = 1: df + 1 - 1
             row_scale = (P2 + scale * T2[ai] - factors[i]["q"][ai]) / df                   # BI:42, :87
             col_scale = sol["c"] + 1.0                                                     # BI:84
@@ -184,7 +229,7 @@ class Algorithm1:
         a = self.ops.systematic_resample(u, (ll_aux + log_weights).contiguous())       # :342-347
         new_state = self._draw_states(rand, time, state, int_var, a)                       # :350-353
         new_int_var, new_basis = self._draw_int_vars(rand, time, new_state, suff_stats, a, factors, scale=lam)   # :358-367
-        new_stats = tuple(self.ops.stats_gather_update(lam, a, suff_stats[i], new_basis[i], new_int_var[i].reshape(-1))
+        new_stats = tuple(self.ops.stats_gather_update(lam, a, suff_stats[i], new_basis[i], new_int_var[i].reshape(-1) if self.nvar[i] == 1 else new_int_var[i])
                           for i in range(self.N_int))                                      # :370-377
         new_lw = self.SSM.log_likelihood(self._obs(time), new_state, self._inp(time), *new_int_var) - ll_aux[a.long()]   # :380-390
         return new_lw, new_state, new_int_var, new_stats, a

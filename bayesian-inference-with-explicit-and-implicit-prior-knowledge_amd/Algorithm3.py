@@ -19,6 +19,9 @@ class Algorithm3(Algorithm1):
                  basis_fcn, device=None):
         super().__init__(N_samples, observations, inputs, SSM, 1.0, init_state_mean, init_state_cov, init_int_var_mean, init_int_var_cov,
                          GP_prior, basis_fcn, device=device)
+        if any(nv != 1 for nv in self.nvar):
+            raise NotImplementedError("Algorithm3 on the device takes scalar interface variables (n = 1, every configuration of the reference); "
+                                      "Algorithm1 handles n > 1")
 
     def _log_base_measure(self, i, stats, ref=None, sol=None):
         """vmap(BI.prior_mniw_log_base_measure) (BI:111-124) of prior + stats (+ ref) for n = 1: multigammaln(a, 1) = lgamma(a).

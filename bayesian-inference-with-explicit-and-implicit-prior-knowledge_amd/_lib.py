@@ -41,6 +41,7 @@ EXPORTS = [
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_layout", "pgas_shard_block", "pgas_shard_set_peer_block", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
     "pgas_hip_runtime_version", "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
     "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_student_t_host", "pgas_m_rng_chi2", "pgas_m_set_time_source", "pgas_m_rng_uniform_dev", "pgas_systematic_resample_dev", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
+    "pgas_m_mniw_solve_n", "pgas_m_mniw_trisolve_n", "pgas_m_stats_gather_update_n", "pgas_m_weighted_stats_n",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)   # pgas_allgather_fn (include/pgas_hip.h)
@@ -166,6 +167,14 @@ def load():
     L.pgas_m_mniw_solve.argtypes = [vp, i64, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pgas_m_mniw_trisolve.restype = C.c_int
     L.pgas_m_mniw_trisolve.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_mniw_solve_n.restype = C.c_int
+    L.pgas_m_mniw_solve_n.argtypes = [vp, i64, i32, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_mniw_trisolve_n.restype = C.c_int
+    L.pgas_m_mniw_trisolve_n.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_weighted_stats_n.restype = C.c_int
+    L.pgas_m_weighted_stats_n.argtypes = [vp, i64, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_stats_gather_update_n.restype = C.c_int
+    L.pgas_m_stats_gather_update_n.argtypes = [vp, i64, i32, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pgas_m_weighted_stats.restype = C.c_int
     L.pgas_m_weighted_stats.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pgas_m_check.restype = C.c_int
@@ -624,32 +633,46 @@ class MarginalOps:
 
     def mniw_solve(self, P0, P1, T0, T1, scale=1.0, anc=None, R0=None, R1=None, phi=None, want=("m", "c", "q", "logdet"), keep_factor=False):
         """eta0 = P0 + scale T0[anc] (+R0), eta1 = P1 + scale T1[anc] (+R1) per particle -> dict of (n,) tensors (see pgas_m_mniw_solve).
-        keep_factor=True adds "L" (n, (M+2)(M+3)/2), the packed factor with the right-hand-side rows, for mniw_trisolve."""
+        keep_factor=True adds "L" (n, (M+2)(M+3)/2), the packed factor with the right-hand-side rows, for mniw_trisolve.
+        T0 (n, M, nvar) with P0 (M, nvar): an interface variable of nvar components (pgas_m_mniw_solve_n) -- "m" is then (n, nvar), "q"
+        (n, nvar, nvar) and "L" (n, (M+1+nvar)(M+2+nvar)/2)."""
         n, M = T0.shape[0], T0.shape[1]
-        out = {k: self._vec(n) for k in want}
+        nv = T0.shape[2] if T0.dim() == 3 else 0   # 0: the scalar layout (T0 (n, M))
+        if nv:
+            if P0.shape != (M, nv) or (R0 is not None and R0.shape != (M, nv)):
+                raise ValueError("mniw_solve: P0 / R0 must be (M, nvar) when T0 is (n, M, nvar)")
+            shp = {"m": (n, nv), "q": (n, nv, nv)}
+            out = {k: torch.empty(shp.get(k, (n,)), dtype=torch.float64, device=self.device) for k in want}
+        else:
+            out = {k: self._vec(n) for k in want}
         if keep_factor:
-            out["L"] = torch.empty((n, (M + 2) * (M + 3) // 2), dtype=torch.float64, device=self.device)
+            R = M + 1 + max(nv, 1)
+            out["L"] = torch.empty((n, R * (R + 1) // 2), dtype=torch.float64, device=self.device)
+            if nv:
+                out["nvar"] = nv
         a = None if anc is None else anc.to(device=self.device, dtype=torch.int32).contiguous()
         for arr in (P0, P1, T0, T1, R0, R1, phi):
             if arr is not None and not (arr.is_contiguous() and arr.dtype == torch.float64 and arr.device == self.device):
                 raise ValueError("mniw_solve: operands must be contiguous fp64 tensors on the engine's device")
         if a is not None and a.numel() != n:
             raise ValueError("mniw_solve: one ancestor index per particle expected")
-        self.eng._chk(self.lib.pgas_m_mniw_solve(self.eng._h, n, M, float(scale), self._ptr(a), P0.data_ptr(), P1.data_ptr(), T0.data_ptr(), T1.data_ptr(),
-                                                 self._ptr(R0), self._ptr(R1), self._ptr(phi), self._ptr(out.get("m")), self._ptr(out.get("c")),
-                                                 self._ptr(out.get("q")), self._ptr(out.get("logdet")), self._ptr(out.get("L")), self.eng._stream()),
+        self.eng._chk(self.lib.pgas_m_mniw_solve_n(self.eng._h, n, M, max(nv, 1), float(scale), self._ptr(a), P0.data_ptr(), P1.data_ptr(), T0.data_ptr(),
+                                                   T1.data_ptr(), self._ptr(R0), self._ptr(R1), self._ptr(phi), self._ptr(out.get("m")), self._ptr(out.get("c")),
+                                                   self._ptr(out.get("q")), self._ptr(out.get("logdet")), self._ptr(out.get("L")), self.eng._stream()),
                       "pgas_m_mniw_solve")
         return out
 
     def mniw_trisolve(self, fac, anc, phi):
         """m = w[anc] . v, c = v . v with v = L[anc]^-1 phi for a factor kept by mniw_solve(keep_factor=True)."""
         n, M = phi.shape
+        nv = int(fac.get("nvar", 0))
+        R = M + 1 + max(nv, 1)
         a = None if anc is None else anc.to(device=self.device, dtype=torch.int32).contiguous()
-        if fac["L"].shape != (n, (M + 2) * (M + 3) // 2) or (a is not None and a.numel() != n):
+        if fac["L"].shape != (n, R * (R + 1) // 2) or (a is not None and a.numel() != n):
             raise ValueError("mniw_trisolve: operand shapes do not match")
-        m, c = self._vec(n), self._vec(n)
-        self.eng._chk(self.lib.pgas_m_mniw_trisolve(self.eng._h, n, M, self._ptr(a), fac["L"].data_ptr(), phi.contiguous().data_ptr(),
-                                                    m.data_ptr(), c.data_ptr(), self.eng._stream()), "pgas_m_mniw_trisolve")
+        m, c = (torch.empty((n, nv), dtype=torch.float64, device=self.device) if nv else self._vec(n)), self._vec(n)
+        self.eng._chk(self.lib.pgas_m_mniw_trisolve_n(self.eng._h, n, M, max(nv, 1), self._ptr(a), fac["L"].data_ptr(), phi.contiguous().data_ptr(),
+                                                      m.data_ptr(), c.data_ptr(), self.eng._stream()), "pgas_m_mniw_trisolve")
         return {"m": m, "c": c}
 
     def check(self):
@@ -659,30 +682,37 @@ class MarginalOps:
     def stats_gather_update(self, scale, anc, T, phi, xi):
         """T = (T0 (n,M), T1 (n,M,M), T2 (n,), T3 (n,)) -> scale * T[anc] + statistics of (xi, phi); new tensors."""
         T0, T1, T2, T3 = T
-        n, M = T0.shape
+        n, M = T0.shape[0], T0.shape[1]
+        nv = T0.shape[2] if T0.dim() == 3 else 1   # T0 (n, M, nvar), T2 (n, nvar, nvar), xi (n, nvar): several components
         out = (torch.empty_like(T0), torch.empty_like(T1), torch.empty_like(T2), torch.empty_like(T3))
         a = None if anc is None else anc.to(device=self.device, dtype=torch.int32).contiguous()
         if a is not None and a.numel() != n:
             raise ValueError("stats_gather_update: one ancestor index per particle expected")
-        if phi.shape != (n, M) or xi.numel() != n or T1.shape != (n, M, M):
-            raise ValueError("stats_gather_update: operand shapes do not match (n, M)")
-        self.eng._chk(self.lib.pgas_m_stats_gather_update(self.eng._h, n, M, float(scale), self._ptr(a), T0.data_ptr(), T1.data_ptr(), T2.data_ptr(),
-                                                          T3.data_ptr(), phi.contiguous().data_ptr(), xi.contiguous().data_ptr(), out[0].data_ptr(),
-                                                          out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), self.eng._stream()),
+        if phi.shape != (n, M) or xi.numel() != n * nv or T1.shape != (n, M, M) or T2.numel() != n * nv * nv:
+            raise ValueError("stats_gather_update: operand shapes do not match (n, M[, nvar])")
+        for arr in (T0, T1, T2, T3):
+            if not arr.is_contiguous():
+                raise ValueError("stats_gather_update: the statistics must be contiguous")
+        self.eng._chk(self.lib.pgas_m_stats_gather_update_n(self.eng._h, n, M, nv, float(scale), self._ptr(a), T0.data_ptr(), T1.data_ptr(), T2.data_ptr(),
+                                                            T3.data_ptr(), phi.contiguous().data_ptr(), xi.contiguous().data_ptr(), out[0].data_ptr(),
+                                                            out[1].data_ptr(), out[2].data_ptr(), out[3].data_ptr(), self.eng._stream()),
                       "pgas_m_stats_gather_update")
         return out
 
     def weighted_stats(self, w, T):
         """sum_p w[p] T[p] for T = (T0 (n,M), T1 (n,M,M), T2 (n,), T3 (n,)) -> (S0 (M,), S1 (M,M), S2 (), S3 ())."""
         T0, T1, T2, T3 = T
-        n, M = T0.shape
+        n, M = T0.shape[0], T0.shape[1]
+        nv = T0.shape[2] if T0.dim() == 3 else 0
         w = w.contiguous()
-        S0, S1 = torch.empty(M, dtype=torch.float64, device=self.device), torch.empty((M, M), dtype=torch.float64, device=self.device)
-        S23 = torch.empty(2, dtype=torch.float64, device=self.device)
-        self.eng._chk(self.lib.pgas_m_weighted_stats(self.eng._h, n, M, w.data_ptr(), T0.data_ptr(), T1.data_ptr(), T2.data_ptr(), T3.data_ptr(),
-                                                     S0.data_ptr(), S1.data_ptr(), S23.data_ptr(), S23.data_ptr() + 8, self.eng._stream()),
+        S0 = torch.empty((M, nv) if nv else (M,), dtype=torch.float64, device=self.device)
+        S1 = torch.empty((M, M), dtype=torch.float64, device=self.device)
+        k = max(nv, 1)
+        S23 = torch.empty(k * k + 1, dtype=torch.float64, device=self.device)
+        self.eng._chk(self.lib.pgas_m_weighted_stats_n(self.eng._h, n, M, k, w.data_ptr(), T0.data_ptr(), T1.data_ptr(), T2.data_ptr(), T3.data_ptr(),
+                                                       S0.data_ptr(), S1.data_ptr(), S23.data_ptr(), S23.data_ptr() + 8 * k * k, self.eng._stream()),
                       "pgas_m_weighted_stats")
-        return S0, S1, S23[0], S23[1]
+        return S0, S1, (S23[: k * k].reshape(k, k) if nv else S23[0]), S23[k * k]
 
     def systematic_resample(self, u, logw):
         return self.eng.systematic_resample(u, logw)

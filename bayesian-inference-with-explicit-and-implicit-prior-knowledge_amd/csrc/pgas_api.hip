@@ -1849,9 +1849,16 @@ int pgas_m_rng_chi2(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t, int
 
 int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int32_t* anc, const double* P0, const double* P1, const double* T0, const double* T1,
                       const double* R0, const double* R1, const double* phi, double* m, double* cc, double* q, double* logdet, double* Lfac, void* sh) {
+    return pgas_m_mniw_solve_n(c, n, M, 1, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q, logdet, Lfac, sh);
+}
+
+int pgas_m_mniw_solve_n(pgas_ctx* c, int64_t n, int32_t M, int32_t nv, double scale, const int32_t* anc, const double* P0, const double* P1, const double* T0,
+                        const double* T1, const double* R0, const double* R1, const double* phi, double* m, double* cc, double* q, double* logdet, double* Lfac,
+                        void* sh) {
     if (!c) return PGAS_E_ARG;
     if (!P0 || !P1 || !T0 || !T1 || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: NULL argument");
-    if (M < 1 || M > PG_MN_MAXM_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: M = %d outside [1, %d]", M, PG_MN_MAXM_WIDE);
+    if (nv < 1 || nv > 8) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: %d components of the interface variable outside [1, 8]", nv);
+    if (M < 1 || M + 1 + nv > PG_MN_MAXROWS_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: M = %d outside [1, %d]", M, PG_MN_MAXROWS_WIDE - 1 - nv);
     if ((R0 == nullptr) != (R1 == nullptr)) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_solve: R0 and R1 must be given together");
     if (n == 0) return PGAS_OK;
     DeviceGuard guard(c->device);
@@ -1860,11 +1867,11 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
         HIPCHK(c, hipMalloc(&c->d_fail, sizeof(int32_t)));
         HIPCHK(c, hipMemsetAsync(c->d_fail, 0, sizeof(int32_t), st));
     }
-    if (M > PG_MN_MAXM || c->mniw_valu == 2) {
-        // 63 ... 126 basis functions (or the test knob): two rows per lane, the triangle in LDS
-        const size_t lds = (size_t)((M + 2) * (M + 3) / 2) * sizeof(double);
+    if (M > PG_MN_MAXM || nv > 1 || c->mniw_valu == 2) {
+        // 63 ... 126 basis functions, several components (or the test knob): two rows per lane, the triangle in LDS
+        const size_t lds = (size_t)((M + 1 + nv) * (M + 2 + nv) / 2) * sizeof(double);
         if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)k_mniw_solve_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mniw_solve_wide, dim3((unsigned)n), dim3(64), lds, st, n, M, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q, logdet, Lfac, c->d_fail);
+        hipLaunchKernelGGL(k_mniw_solve_wide, dim3((unsigned)n), dim3(64), lds, st, n, M, nv, scale, anc, P0, P1, T0, T1, R0, R1, phi, m, cc, q, logdet, Lfac, c->d_fail);
     } else if (c->mniw_valu) {
         const int MT = M <= 22 ? 24 : M <= 30 ? 32 : M <= 42 ? 44 : M <= 46 ? 48 : 64;   // rows: M + 2 (the right-hand sides ride along)
         const int waves = MT == 64 ? 2 : 4;   // LDS: waves x MT (MT+1)/2 doubles <= 64 KB
@@ -1887,15 +1894,20 @@ int pgas_m_mniw_solve(pgas_ctx* c, int64_t n, int32_t M, double scale, const int
 }
 
 int pgas_m_mniw_trisolve(pgas_ctx* c, int64_t n, int32_t M, const int32_t* anc, const double* Lfac, const double* phi, double* m, double* cc, void* sh) {
+    return pgas_m_mniw_trisolve_n(c, n, M, 1, anc, Lfac, phi, m, cc, sh);
+}
+
+int pgas_m_mniw_trisolve_n(pgas_ctx* c, int64_t n, int32_t M, int32_t nv, const int32_t* anc, const double* Lfac, const double* phi, double* m, double* cc, void* sh) {
     if (!c) return PGAS_E_ARG;
     if (!Lfac || !phi || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: NULL argument");
-    if (M < 1 || M > PG_MN_MAXM_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: M = %d outside [1, %d]", M, PG_MN_MAXM_WIDE);
+    if (nv < 1 || nv > 8) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: %d components of the interface variable outside [1, 8]", nv);
+    if (M < 1 || M + 1 + nv > PG_MN_MAXROWS_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_trisolve: M = %d outside [1, %d]", M, PG_MN_MAXROWS_WIDE - 1 - nv);
     if (n == 0) return PGAS_OK;
     DeviceGuard guard(c->device);
-    if (M > PG_MN_MAXM || c->mniw_valu == 2) {
-        const size_t lds = (size_t)((M + 2) * (M + 3) / 2) * sizeof(double);
+    if (M > PG_MN_MAXM || nv > 1 || c->mniw_valu == 2) {
+        const size_t lds = (size_t)((M + 1 + nv) * (M + 2 + nv) / 2) * sizeof(double);
         if (lds > 64 * 1024) HIPCHK(c, hipFuncSetAttribute((const void*)k_mniw_trisolve_wide, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_mniw_trisolve_wide, dim3((unsigned)n), dim3(64), lds, (hipStream_t)sh, n, M, anc, Lfac, phi, m, cc);
+        hipLaunchKernelGGL(k_mniw_trisolve_wide, dim3((unsigned)n), dim3(64), lds, (hipStream_t)sh, n, M, nv, anc, Lfac, phi, m, cc);
         KCHK(c, "k_mniw_trisolve_wide");
         return PGAS_OK;
     }
@@ -1922,25 +1934,38 @@ int pgas_m_check(pgas_ctx* c, void* sh) {
 int pgas_m_stats_gather_update(pgas_ctx* c, int64_t n, int32_t M, double scale, const int32_t* anc, const double* T0i, const double* T1i,
                                const double* T2i, const double* T3i, const double* phi, const double* xi, double* T0o, double* T1o, double* T2o,
                                double* T3o, void* sh) {
+    return pgas_m_stats_gather_update_n(c, n, M, 1, scale, anc, T0i, T1i, T2i, T3i, phi, xi, T0o, T1o, T2o, T3o, sh);
+}
+
+int pgas_m_stats_gather_update_n(pgas_ctx* c, int64_t n, int32_t M, int32_t nv, double scale, const int32_t* anc, const double* T0i, const double* T1i,
+                                 const double* T2i, const double* T3i, const double* phi, const double* xi, double* T0o, double* T1o, double* T2o,
+                                 double* T3o, void* sh) {
     if (!c) return PGAS_E_ARG;
+    if (nv < 1 || nv > 8) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: %d components of the interface variable outside [1, 8]", nv);
     if (!T0i || !T1i || !T2i || !T3i || !phi || !xi || !T0o || !T1o || !T2o || !T3o || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: NULL argument");
     if (T0i == T0o || T1i == T1o || T2i == T2o || T3i == T3o) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: input and output alias");
     if (M < 1 || M > PG_MN_MAXM_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_stats_gather_update: M = %d outside [1, %d]", M, PG_MN_MAXM_WIDE);
     if (n == 0) return PGAS_OK;
     DeviceGuard guard(c->device);
-    hipLaunchKernelGGL(k_stats_gather_update, dim3((unsigned)n), dim3(256), 0, (hipStream_t)sh, n, M, scale, anc, T0i, T1i, T2i, T3i, phi, xi, T0o, T1o, T2o, T3o);
+    hipLaunchKernelGGL(k_stats_gather_update, dim3((unsigned)n), dim3(256), 0, (hipStream_t)sh, n, M, nv, scale, anc, T0i, T1i, T2i, T3i, phi, xi, T0o, T1o, T2o, T3o);
     KCHK(c, "k_stats_gather_update");
     return PGAS_OK;
 }
 
 int pgas_m_weighted_stats(pgas_ctx* c, int64_t n, int32_t M, const double* w, const double* T0, const double* T1, const double* T2, const double* T3,
                           double* S0, double* S1, double* S2, double* S3, void* sh) {
+    return pgas_m_weighted_stats_n(c, n, M, 1, w, T0, T1, T2, T3, S0, S1, S2, S3, sh);
+}
+
+int pgas_m_weighted_stats_n(pgas_ctx* c, int64_t n, int32_t M, int32_t nv, const double* w, const double* T0, const double* T1, const double* T2, const double* T3,
+                            double* S0, double* S1, double* S2, double* S3, void* sh) {
     if (!c) return PGAS_E_ARG;
+    if (nv < 1 || nv > 8) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: %d components of the interface variable outside [1, 8]", nv);
     if (!w || !T0 || !T1 || !T2 || !T3 || !S0 || !S1 || !S2 || !S3 || n < 1) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: bad argument");
     if (M < 1 || M > PG_MN_MAXM_WIDE) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: M = %d outside [1, %d]", M, PG_MN_MAXM_WIDE);
     DeviceGuard guard(c->device);
     hipStream_t st = (hipStream_t)sh;
-    const int ncol = M * M + M + 2;
+    const int ncol = M * M + M * nv + nv * nv + 1;
     const int64_t nchunk = (n + PG_WS_CHUNK - 1) / PG_WS_CHUNK;
     if (nchunk > 65535) FAIL(c, PGAS_E_ARG, "pgas_m_weighted_stats: n = %lld too large", (long long)n);
     const size_t need = (size_t)nchunk * ncol * sizeof(double);
@@ -1952,9 +1977,9 @@ int pgas_m_weighted_stats(pgas_ctx* c, int64_t n, int32_t M, const double* w, co
         HIPCHK(c, hipMalloc(&c->ws_partial, need));
         c->ws_bytes = need;
     }
-    hipLaunchKernelGGL(k_weighted_stats_partial, dim3((ncol + 255) / 256, (unsigned)nchunk), dim3(256), 0, st, n, M, w, T0, T1, T2, T3, c->ws_partial);
+    hipLaunchKernelGGL(k_weighted_stats_partial, dim3((ncol + 255) / 256, (unsigned)nchunk), dim3(256), 0, st, n, M, nv, w, T0, T1, T2, T3, c->ws_partial);
     KCHK(c, "k_weighted_stats_partial");
-    hipLaunchKernelGGL(k_weighted_stats_final, dim3((ncol + 255) / 256), dim3(256), 0, st, (int)nchunk, M, c->ws_partial, S0, S1, S2, S3);
+    hipLaunchKernelGGL(k_weighted_stats_final, dim3((ncol + 255) / 256), dim3(256), 0, st, (int)nchunk, M, nv, c->ws_partial, S0, S1, S2, S3);
     KCHK(c, "k_weighted_stats_final");
     return PGAS_OK;
 }

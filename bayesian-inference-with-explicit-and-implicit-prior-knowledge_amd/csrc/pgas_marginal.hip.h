@@ -375,9 +375,13 @@ __global__ __launch_bounds__(256) void k_mniw_trisolve(int64_t n, int M, const i
 // 1 / sqrt by v_rsq_f64 + two Newton steps, A[r][j] = fma(-L[r][k], L[j][k], A[r][j]) for k ascending, right-hand sides as two extra
 // rows), so that for M <= 62 the results are bit-identical to it (tests/test_gpu_marginal.py).  A generality path, not a fast one:
 // every FMA costs two LDS reads and a write.
+// The same kernels carry interface variables with nv > 1 components (eta0 is (M, nv): BI:18-50 are general in n): the nv columns of
+// eta0 are nv extra rows of the augmented matrix, M + 1 + nv <= 128 rows in all; the Schur complement of the corner then holds
+// c = v.v, m_j = w_j.v and Q_jk = w_j.w_k (row_scale = eta2 - Q, BI:42).  nv = 1 is the scalar case above, bit for bit.
 // ------------------------------------------------------------------------------------------
 #define PG_MN_MAXM_WIDE 126
-__global__ __launch_bounds__(64) void k_mniw_solve_wide(int64_t n, int M, double scale, const int32_t* __restrict__ anc, const double* __restrict__ P0,
+#define PG_MN_MAXROWS_WIDE 128
+__global__ __launch_bounds__(64) void k_mniw_solve_wide(int64_t n, int M, int nv, double scale, const int32_t* __restrict__ anc, const double* __restrict__ P0,
                                                          const double* __restrict__ P1, const double* __restrict__ T0,
                                                          const double* __restrict__ T1, const double* __restrict__ R0,
                                                          const double* __restrict__ R1, const double* __restrict__ phi,
@@ -391,25 +395,25 @@ __global__ __launch_bounds__(64) void k_mniw_solve_wide(int64_t n, int M, double
     const int64_t src = anc ? (int64_t)anc[p] : p;
     double* __restrict__ A = smem;
     const double* __restrict__ T1p = T1 + (size_t)src * M * M;
-    const int R = M + 2;
+    const int R = M + 1 + nv;
     for (int r = 0; r < M; ++r)
         for (int j = lane; j <= r; j += 64) {
             double v = P1[r * M + j] + scale * T1p[r * M + j];
             if (R1) v += R1[r * M + j];
             A[r * (r + 1) / 2 + j] = v;
         }
-    const int tM = M * (M + 1) / 2, tM1 = (M + 1) * (M + 2) / 2;   // starts of rows M and M+1
+    const int tM = M * (M + 1) / 2;   // start of row M (phi); row M + 1 + v holds column v of eta0
     for (int j = lane; j < M; j += 64) {
-        double w = P0[j] + scale * T0[(size_t)src * M + j];
-        if (R0) w += R0[j];
         A[tM + j] = phi ? phi[(size_t)p * M + j] : 0.0;
-        A[tM1 + j] = w;
+        for (int v = 0; v < nv; ++v) {
+            double w = P0[j * nv + v] + scale * T0[((size_t)src * M + j) * nv + v];
+            if (R0) w += R0[j * nv + v];
+            A[(M + 1 + v) * (M + 2 + v) / 2 + j] = w;
+        }
     }
-    if (lane == 0) {   // the corner: (M,M), (M+1,M), (M+1,M+1)
-        A[tM + M] = 0.0;
-        A[tM1 + M] = 0.0;
-        A[tM1 + M + 1] = 0.0;
-    }
+    if (lane == 0)   // the corner: rows M ... R-1, columns M ... row
+        for (int r = M; r < R; ++r)
+            for (int cc = M; cc <= r; ++cc) A[r * (r + 1) / 2 + cc] = 0.0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int r0 = lane, r1 = lane + 64;
@@ -440,7 +444,7 @@ __global__ __launch_bounds__(64) void k_mniw_solve_wide(int64_t n, int M, double
         __builtin_amdgcn_wave_barrier();
     }
     if (Lfac_out) {
-        const int tri_out = (M + 2) * (M + 3) / 2;
+        const int tri_out = R * (R + 1) / 2;
         double* __restrict__ dst = Lfac_out + (size_t)p * tri_out;
         for (int e = lane; e < tri_out; e += 64) dst[e] = A[e];
     }
@@ -448,21 +452,29 @@ __global__ __launch_bounds__(64) void k_mniw_solve_wide(int64_t n, int M, double
     const double ld = -2.0 * wave_sum_f64((r0 < M ? pgas_log(d0) : 0.0) + (r1 < M ? pgas_log(d1) : 0.0));
     if (lane == 0) {
         if (c_out) c_out[p] = -A[tM + M];
-        if (m_out) m_out[p] = -A[tM1 + M];
-        if (q_out) q_out[p] = -A[tM1 + M + 1];
+        for (int v = 0; v < nv; ++v) {
+            const int tv = (M + 1 + v) * (M + 2 + v) / 2;
+            if (m_out) m_out[(size_t)p * nv + v] = -A[tv + M];
+            if (q_out)
+                for (int u = 0; u <= v; ++u) {
+                    const double q = -A[tv + M + 1 + u];
+                    q_out[((size_t)p * nv + v) * nv + u] = q;
+                    q_out[((size_t)p * nv + u) * nv + v] = q;
+                }
+        }
         if (logdet_out) logdet_out[p] = ld;
         if (!(ld - ld == 0.0) && fail_out) atomicAdd(fail_out, 1);
     }
 }
 
-__global__ __launch_bounds__(64) void k_mniw_trisolve_wide(int64_t n, int M, const int32_t* __restrict__ anc, const double* __restrict__ Lfac,
+__global__ __launch_bounds__(64) void k_mniw_trisolve_wide(int64_t n, int M, int nv, const int32_t* __restrict__ anc, const double* __restrict__ Lfac,
                                                             const double* __restrict__ phi, double* __restrict__ m_out, double* __restrict__ c_out) {
     extern __shared__ double smem[];
     const int lane = threadIdx.x;
     const int64_t p = blockIdx.x;
     if (p >= n) return;
     const int64_t src = anc ? (int64_t)anc[p] : p;
-    const int tri_n = (M + 2) * (M + 3) / 2;
+    const int tri_n = (M + 1 + nv) * (M + 2 + nv) / 2;
     double* __restrict__ A = smem;
     const double* __restrict__ Ls = Lfac + (size_t)src * tri_n;
     for (int e = lane; e < tri_n; e += 64) A[e] = Ls[e];
@@ -471,8 +483,6 @@ __global__ __launch_bounds__(64) void k_mniw_trisolve_wide(int64_t n, int M, con
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     const int t0 = r0 < M ? r0 * (r0 + 1) / 2 : 0, t1 = r1 < M ? r1 * (r1 + 1) / 2 : 0;
-    const int tw = (M + 1) * (M + 2) / 2;
-    const double w0 = r0 < M ? A[tw + r0] : 0.0, w1 = r1 < M ? A[tw + r1] : 0.0;
     const double di0 = r0 < M ? A[t0 + r0] : 1.0, di1 = r1 < M ? A[t1 + r1] : 1.0;
     for (int k = 0; k < M; ++k) {
         const int kl = k & 63;
@@ -483,16 +493,19 @@ __global__ __launch_bounds__(64) void k_mniw_trisolve_wide(int64_t n, int M, con
         if (r1 == k) b1 = bk;
         else if (r1 > k) b1 = PGAS_FMA(-lk1, bk, b1);
     }
-    const double mm = wave_sum_f64((r0 < M ? w0 * b0 : 0.0) + (r1 < M ? w1 * b1 : 0.0));
-    const double cc = wave_sum_f64((r0 < M ? b0 * b0 : 0.0) + (r1 < M ? b1 * b1 : 0.0));
-    if (lane == 0) {
-        if (m_out) m_out[p] = mm;
-        if (c_out) c_out[p] = cc;
+    for (int v = 0; v < nv; ++v) {   // m_v = w_v . v with w_v = row M + 1 + v of the stored triangle
+        const int tw = (M + 1 + v) * (M + 2 + v) / 2;
+        const double w0 = r0 < M ? A[tw + r0] : 0.0, w1 = r1 < M ? A[tw + r1] : 0.0;
+        const double mm = wave_sum_f64((r0 < M ? w0 * b0 : 0.0) + (r1 < M ? w1 * b1 : 0.0));
+        if (lane == 0 && m_out) m_out[(size_t)p * nv + v] = mm;
     }
+    const double cc = wave_sum_f64((r0 < M ? b0 * b0 : 0.0) + (r1 < M ? b1 * b1 : 0.0));
+    if (lane == 0 && c_out) c_out[p] = cc;
 }
 
 // one workgroup per particle: T_out[p] = scale * T_in[a_p] + update
-__global__ __launch_bounds__(256) void k_stats_gather_update(int64_t n, int M, double scale, const int32_t* __restrict__ anc,
+// nv = components of the interface variable: T0 (n, M, nv), T2 (n, nv, nv), xi (n, nv); nv = 1 is the scalar layout
+__global__ __launch_bounds__(256) void k_stats_gather_update(int64_t n, int M, int nv, double scale, const int32_t* __restrict__ anc,
                                                               const double* __restrict__ T0i, const double* __restrict__ T1i,
                                                               const double* __restrict__ T2i, const double* __restrict__ T3i,
                                                               const double* __restrict__ phi, const double* __restrict__ xi,
@@ -502,11 +515,10 @@ __global__ __launch_bounds__(256) void k_stats_gather_update(int64_t n, int M, d
     const int64_t p = blockIdx.x;
     const int64_t a = anc ? (int64_t)anc[p] : p;
     const int tid = threadIdx.x;
-    const double x = xi[p];
     for (int e = tid; e < M; e += 256) {
         const double f = phi[(size_t)p * M + e];
         sphi[e] = f;
-        T0o[(size_t)p * M + e] = scale * T0i[(size_t)a * M + e] + f * x;
+        for (int v = 0; v < nv; ++v) T0o[((size_t)p * M + e) * nv + v] = scale * T0i[((size_t)a * M + e) * nv + v] + f * xi[(size_t)p * nv + v];
     }
     __syncthreads();
     const double* __restrict__ src = T1i + (size_t)a * M * M;
@@ -515,10 +527,11 @@ __global__ __launch_bounds__(256) void k_stats_gather_update(int64_t n, int M, d
         const int r = e / M, c = e - r * M;
         dst[e] = scale * src[e] + sphi[r] * sphi[c];
     }
-    if (tid == 0) {
-        T2o[p] = scale * T2i[a] + x * x;
-        T3o[p] = scale * T3i[a] + 1.0;
+    if (tid < nv * nv) {
+        const int v = tid / nv, u = tid - v * nv;
+        T2o[(size_t)p * nv * nv + tid] = scale * T2i[(size_t)a * nv * nv + tid] + xi[(size_t)p * nv + v] * xi[(size_t)p * nv + u];
     }
+    if (tid == 0) T3o[p] = scale * T3i[a] + 1.0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -529,17 +542,17 @@ __global__ __launch_bounds__(256) void k_stats_gather_update(int64_t n, int M, d
 // partial sums per chunk, then a second pass adds the chunks in index order (deterministic, no atomics).
 // ------------------------------------------------------------------------------------------
 #define PG_WS_CHUNK 512
-__device__ __forceinline__ double ws_column(int col, int M, int64_t p, const double* __restrict__ T0, const double* __restrict__ T1,
+__device__ __forceinline__ double ws_column(int col, int M, int nv, int64_t p, const double* __restrict__ T0, const double* __restrict__ T1,
                                             const double* __restrict__ T2, const double* __restrict__ T3) {
-    const int mm = M * M;
+    const int mm = M * M, m0 = M * nv, m2 = nv * nv;   // record = [T1 | T0 | T2 | T3]
     if (col < mm) return T1[(size_t)p * mm + col];
-    if (col < mm + M) return T0[(size_t)p * M + (col - mm)];
-    return col == mm + M ? T2[p] : T3[p];
+    if (col < mm + m0) return T0[(size_t)p * m0 + (col - mm)];
+    return col < mm + m0 + m2 ? T2[(size_t)p * m2 + (col - mm - m0)] : T3[p];
 }
-__global__ __launch_bounds__(256) void k_weighted_stats_partial(int64_t n, int M, const double* __restrict__ w, const double* __restrict__ T0,
+__global__ __launch_bounds__(256) void k_weighted_stats_partial(int64_t n, int M, int nv, const double* __restrict__ w, const double* __restrict__ T0,
                                                                  const double* __restrict__ T1, const double* __restrict__ T2,
                                                                  const double* __restrict__ T3, double* __restrict__ partial) {
-    const int ncol = M * M + M + 2;
+    const int ncol = M * M + M * nv + nv * nv + 1;
     const int col = blockIdx.x * 256 + threadIdx.x;
     const int64_t p0 = (int64_t)blockIdx.y * PG_WS_CHUNK;
     const int64_t p1 = p0 + PG_WS_CHUNK < n ? p0 + PG_WS_CHUNK : n;
@@ -547,15 +560,15 @@ __global__ __launch_bounds__(256) void k_weighted_stats_partial(int64_t n, int M
     double acc0 = 0.0, acc1 = 0.0;  // two chains: the loads of consecutive particles overlap
     int64_t p = p0;
     for (; p + 1 < p1; p += 2) {
-        acc0 = PGAS_FMA(w[p], ws_column(col, M, p, T0, T1, T2, T3), acc0);
-        acc1 = PGAS_FMA(w[p + 1], ws_column(col, M, p + 1, T0, T1, T2, T3), acc1);
+        acc0 = PGAS_FMA(w[p], ws_column(col, M, nv, p, T0, T1, T2, T3), acc0);
+        acc1 = PGAS_FMA(w[p + 1], ws_column(col, M, nv, p + 1, T0, T1, T2, T3), acc1);
     }
-    if (p < p1) acc0 = PGAS_FMA(w[p], ws_column(col, M, p, T0, T1, T2, T3), acc0);
+    if (p < p1) acc0 = PGAS_FMA(w[p], ws_column(col, M, nv, p, T0, T1, T2, T3), acc0);
     partial[(size_t)blockIdx.y * ncol + col] = acc0 + acc1;
 }
-__global__ __launch_bounds__(256) void k_weighted_stats_final(int nchunk, int M, const double* __restrict__ partial, double* __restrict__ S0,
+__global__ __launch_bounds__(256) void k_weighted_stats_final(int nchunk, int M, int nv, const double* __restrict__ partial, double* __restrict__ S0,
                                                                double* __restrict__ S1, double* __restrict__ S2, double* __restrict__ S3) {
-    const int ncol = M * M + M + 2, mm = M * M;
+    const int mm = M * M, m0 = M * nv, m2 = nv * nv, ncol = mm + m0 + m2 + 1;
     const int col = blockIdx.x * 256 + threadIdx.x;
     if (col >= ncol) return;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four chains in a fixed interleaving: deterministic, and the loads overlap
@@ -569,7 +582,7 @@ __global__ __launch_bounds__(256) void k_weighted_stats_final(int nchunk, int M,
     for (; c < nchunk; ++c) a0 += partial[(size_t)c * ncol + col];
     const double acc = (a0 + a1) + (a2 + a3);
     if (col < mm) S1[col] = acc;
-    else if (col < mm + M) S0[col - mm] = acc;
-    else if (col == mm + M) S2[0] = acc;
+    else if (col < mm + m0) S0[col - mm] = acc;
+    else if (col < mm + m0 + m2) S2[col - mm - m0] = acc;
     else S3[0] = acc;
 }

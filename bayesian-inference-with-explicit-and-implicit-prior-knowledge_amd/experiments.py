@@ -247,6 +247,42 @@ def smo_marginal(T=750, seed=12345678):
                            np.diag([1e-4, 1e-4]), [np.array([0.0])], [np.diag([1e-12])], [prior], [basis.on([0, 1])], 0.999, model, X, [F_sd])
 
 
+def smo_two_component_marginal(T=750, seed=12345678):
+    """NOT a configuration of the reference (all of them have scalar interface variables): the SingleMassOscillator with its force split
+    into a spring part and a damper part, learnt as ONE latent function with n = 2 components over the same basis -- the case the
+    reference's MNIW formulas (BI:18-108, eta0 (M, n), eta2 (n, n)) are written for.  Exercises the n > 1 path of Algorithm1."""
+    m, dt = 0.2, 0.02
+    pg = smo_pgas(T=T, seed=seed)
+    X = pg.X_true
+    c1, c2, d1, d2 = 5.0, 2.0, 0.4, 0.4
+    F_s = c1 * X[:, 0] + c2 * X[:, 0] ** 3
+    F_d = d1 * X[:, 1] / (1 + d2 * X[:, 1] * np.tanh(X[:, 1]))
+
+    def model(xp):
+        def dx(x, F, F_sd):
+            return xp.stack([x[:, 1], (-F_sd + F) / m], 1)
+
+        def f_x(state, input, *int_var):
+            F, Fs = input.reshape(-1)[0], int_var[0][:, 0] + int_var[0][:, 1]
+            k1 = dx(state, F, Fs)
+            k2 = dx(state + dt / 2.0 * k1, F, Fs)
+            k3 = dx(state + dt / 2.0 * k2, F, Fs)
+            k4 = dx(state + dt * k3, F, Fs)
+            return state + dt / 6.0 * (k1 + 2 * k2 + 2 * k3 + k4)
+
+        def f_y(state, input, *int_var):
+            return state[:, 0:1]
+
+        return f_x, f_y
+
+    basis = pg.basis_fcn.basis
+    sd = np.diag(np.linalg.inv(pg.GP_prior[1]))
+    prior = prior_mniw_2naturalPara(np.zeros((2, basis.M)), np.diag(sd), np.array([[1.0, 0.2], [0.2, 0.5]]), 4)
+    return MarginalProblem("SMO-2", pg.observations, pg.inputs.reshape(-1, 1), np.diag([5e-8, 5e-9]), np.array([[1e-3]]), np.array([0.0, 0.0]),
+                           np.diag([1e-4, 1e-4]), [np.array([0.0, 0.0])], [np.array([[1e-12, 2e-13], [2e-13, 1e-12]])], [prior], [basis.on([0, 1])], 0.999,
+                           model, X, [np.stack([F_s, F_d], 1)])
+
+
 def toy_marginal(T=40, seed=12345678):
     """src/Toy_Example.py:14-128: no model knowledge, the transition IS the latent function (x_t = xi_{t-1})."""
     pt = toy(T=T, seed=seed)

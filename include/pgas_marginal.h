@@ -81,6 +81,25 @@ int pgas_m_weighted_stats(pgas_ctx* ctx, int64_t n, int32_t M, const double* w_d
                           const double* T2_dev, const double* T3_dev, double* S0_dev, double* S1_dev, double* S2_dev, double* S3_dev,
                           void* stream_handle);
 
+/* The same four operations for an interface variable with nvar > 1 components (the reference's formulas are general in n: eta0 (M, n),
+ * eta2 (n, n), BI:18-50, 53-61, 64-108; no configuration of the reference uses n > 1).  Layouts: P0 / R0 (M, nvar), T0 (n, M, nvar),
+ * T2 (n, nvar, nvar), xi (n, nvar), all row-major; results m (n, nvar) = eta0^T eta1^-1 phi (BI:81), q (n, nvar, nvar) = eta0^T eta1^-1 eta0
+ * (row_scale = eta2 - q, BI:42), c and logdet as above; Lfac (n, (M+1+nvar)(M+2+nvar)/2) carries nvar right-hand-side rows behind the
+ * factor.  M + 1 + nvar <= 128, nvar <= 8.  nvar = 1 is exactly the scalar entry point (which forwards here). */
+int pgas_m_mniw_solve_n(pgas_ctx* ctx, int64_t n, int32_t M, int32_t nvar, double scale, const int32_t* anc_dev, const double* P0_dev,
+                        const double* P1_dev, const double* T0_dev, const double* T1_dev, const double* R0_dev, const double* R1_dev,
+                        const double* phi_dev, double* m_dev, double* c_dev, double* q_dev, double* logdet_dev, double* Lfac_dev,
+                        void* stream_handle);
+int pgas_m_mniw_trisolve_n(pgas_ctx* ctx, int64_t n, int32_t M, int32_t nvar, const int32_t* anc_dev, const double* Lfac_dev,
+                           const double* phi_dev, double* m_dev, double* c_dev, void* stream_handle);
+int pgas_m_stats_gather_update_n(pgas_ctx* ctx, int64_t n, int32_t M, int32_t nvar, double scale, const int32_t* anc_dev, const double* T0_in,
+                                 const double* T1_in, const double* T2_in, const double* T3_in, const double* phi_dev,
+                                 const double* xi_dev, double* T0_out, double* T1_out, double* T2_out, double* T3_out,
+                                 void* stream_handle);
+int pgas_m_weighted_stats_n(pgas_ctx* ctx, int64_t n, int32_t M, int32_t nvar, const double* w_dev, const double* T0_dev,
+                            const double* T1_dev, const double* T2_dev, const double* T3_dev, double* S0_dev, double* S1_dev,
+                            double* S2_dev, double* S3_dev, void* stream_handle);
+
 #ifdef __cplusplus
 }
 #endif

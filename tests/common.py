@@ -84,8 +84,9 @@ class CanonRand:
         return canon.uniform(self.seed, stream, t)
 
     def student_t(self, stream, t, nu, n=1):
-        assert n == 1
-        return canon.student_t(self.seed, stream, t, 0, np.broadcast_to(np.asarray(nu, dtype=np.float64), (self.N,)).copy()).reshape(self.N, 1)
+        """(N, n): component j of an n-component interface variable draws from stream + 16 j (pgas_amd.Algorithm1._draw_int_vars)."""
+        nu = np.broadcast_to(np.asarray(nu, dtype=np.float64), (self.N,)).copy()
+        return np.stack([canon.student_t(self.seed, stream + 16 * j, t, 0, nu) for j in range(n)], axis=1)
 
 
 def marginal_oracle(problem, N, kind="Algorithm1"):

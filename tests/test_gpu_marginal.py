@@ -48,6 +48,80 @@ def test_mniw_solve_wide_bases(N, M):
     _check_mniw_solve(ops, N, M)
 
 
+@pytest.mark.parametrize("N,M,nv", [(200, 41, 2), (130, 20, 3), (65, 100, 2), (64, 119, 8), (50, 7, 4)])
+def test_mniw_kernels_with_several_components(N, M, nv):
+    """Interface variables with nv > 1 components (eta0 (M, nv); BI:18-108 are general in n): solve, stored-factor solve, statistics
+    update and weighted reduction against torch.linalg / einsum."""
+    ops = _ops(N)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    dev = ops.device
+    rnd = lambda *sh: torch.randn(*sh, generator=g, dtype=torch.float64)   # noqa: E731
+    B = rnd(N, M, 3)
+    T1 = (B @ B.transpose(1, 2)).to(dev).contiguous()
+    T0 = rnd(N, M, nv).to(dev)
+    P1 = torch.diag(torch.rand(M, generator=g, dtype=torch.float64) + 0.5).to(dev)
+    P0 = rnd(M, nv).to(dev)
+    phi = rnd(N, M).to(dev)
+    anc = torch.randint(0, N, (N,), generator=g).to(dev).to(torch.int32)
+    idx = anc.long()
+    sol = ops.mniw_solve(P0, P1, T0, T1, scale=0.97, anc=anc, phi=phi, keep_factor=True)
+    eta1, eta0 = P1 + 0.97 * T1[idx], P0 + 0.97 * T0[idx]
+    L = torch.linalg.cholesky(eta1)
+    v = torch.linalg.solve_triangular(L, phi.unsqueeze(-1), upper=False)
+    W = torch.linalg.solve_triangular(L, eta0, upper=False)
+    ref = {"m": (W.transpose(1, 2) @ v).squeeze(-1), "q": W.transpose(1, 2) @ W, "c": (v * v).sum((1, 2)),
+           "logdet": 2 * torch.log(torch.diagonal(L, dim1=1, dim2=2)).sum(1)}
+    for k in ref:
+        assert sol[k].shape == ref[k].shape, k
+        err = (sol[k] - ref[k]).abs().max().item() / max(1.0, ref[k].abs().max().item())
+        assert err < 1e-10, (k, err)
+    assert torch.equal(sol["q"], sol["q"].transpose(1, 2))
+    # the children reuse the factor of their ancestor
+    phi2 = rnd(N, M).to(dev)
+    anc2 = torch.randint(0, N, (N,), generator=g).to(dev).to(torch.int32)
+    tri = ops.mniw_trisolve(sol, anc2, phi2)
+    i2 = anc2.long()
+    v2 = torch.linalg.solve_triangular(L[i2], phi2.unsqueeze(-1), upper=False)
+    for k, r in (("m", (W[i2].transpose(1, 2) @ v2).squeeze(-1)), ("c", (v2 * v2).sum((1, 2)))):
+        assert (tri[k] - r).abs().max().item() / max(1.0, r.abs().max().item()) < 1e-10, k
+    # statistics: T_out = s T_in[a] + (phi xi^T, phi phi^T, xi xi^T, 1)
+    xi = rnd(N, nv).to(dev)
+    T2, T3 = rnd(N, nv, nv).to(dev), torch.rand(N, generator=g, dtype=torch.float64).to(dev)
+    new = ops.stats_gather_update(0.9, anc, (T0, T1, T2, T3), phi, xi)
+    want = (0.9 * T0[idx] + phi[:, :, None] * xi[:, None, :], 0.9 * T1[idx] + phi[:, :, None] * phi[:, None, :],
+            0.9 * T2[idx] + xi[:, :, None] * xi[:, None, :], 0.9 * T3[idx] + 1.0)
+    for a_, b_ in zip(new, want):
+        assert a_.shape == b_.shape and (a_ - b_).abs().max().item() <= 1e-13 * max(1.0, b_.abs().max().item())
+    w = torch.softmax(rnd(N).to(dev), 0)
+    S = ops.weighted_stats(w, new)
+    for s_, t_ in zip(S, new):
+        r_ = torch.einsum("n...,n->...", t_, w)
+        assert s_.shape == r_.shape and (s_ - r_).abs().max().item() <= 1e-12 * max(1.0, r_.abs().max().item())
+
+
+def test_algorithm1_with_a_two_component_interface_variable():
+    """n = 2 (not a configuration of the reference, whose interface variables are scalar; its formulas are general in n): the
+    oscillator's force learnt as spring + damper components of one latent function -- against the NumPy restatement, eager and
+    graph-replayed."""
+    N = 150
+    pb = experiments.smo_two_component_marginal(T=10)
+    ref = marginal_oracle(pb, N)(CanonRand(SEED, N))
+    for use_graph in (False, True):
+        got = _device_alg(pb, N)(SEED, use_graph=use_graph)
+        assert np.array_equal(got[4].cpu().numpy(), ref[4]), "ancestor_trace"
+        _close(got[0], ref[0], "state_trace")
+        _close(got[1][0], ref[1][0], "int_var_trace")
+        assert got[1][0].shape == (pb.T, N, 2)
+        for j in range(4):
+            _close(got[2][0][j], ref[2][0][j], f"suff_stats_trace[{j}]")
+            _close(got[5][0][j], ref[5][0][j], f"suff_stats[{j}]")
+            assert tuple(got[5][0][j].shape) == np.shape(ref[5][0][j])
+        _close(got[3], ref[3], "weights_trace")
+        _close(got[7], ref[7], "log_likelihood", tol=1e-7)
+    with pytest.raises(NotImplementedError):
+        _device_alg(pb, N, "Algorithm3")
+
+
 @pytest.mark.parametrize("N,M", [(300, 41), (257, 62), (70, 14), (64, 1)])
 def test_mniw_wide_kernels_match_the_row_per_lane_kernel_bit_for_bit(N, M):
     """PGAS_OPT_MNIW_VALU = 2 runs the wide kernels at any M: same operations in the same order as the column-by-column kernel (= 1)."""
