@@ -11,7 +11,7 @@ tensors on the GPU.  What runs where:
 
 Limits: M + 1 + n <= 128 per latent function (basis size M, n components of its interface variable; n <= 8).  n = 1 with M <= 62 -- every
 instantiation of the reference -- runs on the fast kernels; wider bases and n > 1 (the reference's formulas, BI:18-108, are general in n) on
-the two-rows-per-lane generality kernels.  Algorithm3 (conditional filter) takes n = 1 only.
+the two-rows-per-lane generality kernels (Algorithm3 and Algorithm2 included).
 `key` is an integer seed (own Philox streams, include/pgas_canon.h) or an object with the provider interface of `DeviceRand`.
 """
 from __future__ import annotations

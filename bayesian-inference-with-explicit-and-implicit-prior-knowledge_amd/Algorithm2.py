@@ -33,6 +33,10 @@ class Algorithm2:
                 basis = bf.trajectory(state_traj, c.inputs.reshape(self.N_steps, -1))
             else:                              # arbitrary user callables keep the reference's per-step call
                 basis = torch.stack([bf(state_traj[t:t + 1], c.inputs[t]).reshape(-1) for t in range(self.N_steps)])   # (T,M)
+            if c.nvar[i] > 1:   # T0 (M, n), T2 (n, n)
+                xi = int_var_traj[i].reshape(self.N_steps, c.nvar[i])
+                out.append((basis.T @ xi, basis.T @ basis, xi.T @ xi, torch.tensor(float(self.N_steps), dtype=torch.float64, device=c.device)))
+                continue
             xi = int_var_traj[i].reshape(-1)
             out.append((basis.T @ xi, basis.T @ basis, (xi * xi).sum(), torch.tensor(float(self.N_steps), dtype=torch.float64, device=c.device)))
         return out
@@ -42,12 +46,13 @@ class Algorithm2:
         nx = c.init_state_mean.numel()
         state_trace = torch.zeros((K, T, nx), dtype=torch.float64, device=dev)                                    # :46-54
         state_trace[0] = _t(init_ref_state.cpu() if isinstance(init_ref_state, torch.Tensor) else init_ref_state, dev).reshape(T, nx)
-        int_var_trace = [torch.zeros((K, T, 1), dtype=torch.float64, device=dev) for _ in range(c.N_int)]         # :56-67
+        int_var_trace = [torch.zeros((K, T, nv), dtype=torch.float64, device=dev) for nv in c.nvar]               # :56-67
         for i in range(c.N_int):
             v = init_ref_int_var[i]
-            int_var_trace[i][0] = _t(v.cpu() if isinstance(v, torch.Tensor) else v, dev).reshape(T, 1)
-        sst = [[torch.zeros((K, M, 1), dtype=torch.float64, device=dev), torch.zeros((K, M, M), dtype=torch.float64, device=dev),
-                torch.zeros((K, 1, 1), dtype=torch.float64, device=dev), torch.zeros((K,), dtype=torch.float64, device=dev)] for M in c.dim_basis]   # :68-79
+            int_var_trace[i][0] = _t(v.cpu() if isinstance(v, torch.Tensor) else v, dev).reshape(T, c.nvar[i])
+        sst = [[torch.zeros((K, M, nv), dtype=torch.float64, device=dev), torch.zeros((K, M, M), dtype=torch.float64, device=dev),
+                torch.zeros((K, nv, nv), dtype=torch.float64, device=dev), torch.zeros((K,), dtype=torch.float64, device=dev)]
+               for M, nv in zip(c.dim_basis, c.nvar)]   # :68-79
         ref_stats = self._trajectory_stats(state_trace[0], [v[0] for v in int_var_trace])                        # :81-93
         for i in range(c.N_int):
             for j in range(4):
@@ -62,9 +67,9 @@ class Algorithm2:
             new_state, new_int_var = c(key_step, state_trace[k - 1], [v[k - 1] for v in int_var_trace],
                                        [[sst[i][j][k - 1] for j in range(4)] for i in range(c.N_int)])            # :122-134
             state_trace[k] = new_state.reshape(T, nx)                                                             # :137
-            stats = self._trajectory_stats(state_trace[k], [v.reshape(T, 1) for v in new_int_var])
+            stats = self._trajectory_stats(state_trace[k], [v.reshape(T, nv) for v, nv in zip(new_int_var, c.nvar)])
             for i in range(c.N_int):
-                int_var_trace[i][k] = new_int_var[i].reshape(T, 1)                                                # :139
+                int_var_trace[i][k] = new_int_var[i].reshape(T, c.nvar[i])                                        # :139
                 for j in range(4):
                     sst[i][j][k] = stats[i][j].reshape(sst[i][j][k].shape)                                        # :140-160
             if progress is not None:

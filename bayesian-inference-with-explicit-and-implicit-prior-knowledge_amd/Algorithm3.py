@@ -9,7 +9,7 @@ import math
 import numpy as np
 import torch
 
-from .Algorithm1 import Algorithm1, STREAM_ANCESTOR, STREAM_FINAL, STREAM_RESAMPLE, _t
+from .Algorithm1 import Algorithm1, STREAM_ANCESTOR, STREAM_FINAL, STREAM_RESAMPLE, _small_cholesky, _t
 
 
 class Algorithm3(Algorithm1):
@@ -19,15 +19,26 @@ class Algorithm3(Algorithm1):
                  basis_fcn, device=None):
         super().__init__(N_samples, observations, inputs, SSM, 1.0, init_state_mean, init_state_cov, init_int_var_mean, init_int_var_cov,
                          GP_prior, basis_fcn, device=device)
-        if any(nv != 1 for nv in self.nvar):
-            raise NotImplementedError("Algorithm3 on the device takes scalar interface variables (n = 1, every configuration of the reference); "
-                                      "Algorithm1 handles n > 1")
 
     def _log_base_measure(self, i, stats, ref=None, sol=None):
         """vmap(BI.prior_mniw_log_base_measure) (BI:111-124) of prior + stats (+ ref) for n = 1: multigammaln(a, 1) = lgamma(a).
         `sol` = (q, logdet) already computed for the same matrices (the auxiliary pass of this step)."""
         P0, P1, P2, P3 = self.GP_prior[i]
         T0, T1, T2, T3 = stats
+        nv = self.nvar[i]
+        if nv > 1:   # the general form (BI:111-124): n M, n log det eta1, multigammaln(nu / 2, n), log det Psi
+            M = P0.shape[0]
+            R0 = R1 = None
+            r2 = r3 = 0.0
+            if ref is not None:
+                R0, R1, r2, r3 = ref[0].reshape(M, nv).contiguous(), ref[1].contiguous(), ref[2].reshape(nv, nv), ref[3].reshape(())
+            if sol is None:
+                sol = self.ops.mniw_solve(P0, P1, T0, T1, R0=R0, R1=R1, want=("q", "logdet"))
+            nu = P3 + T3 + r3
+            Lp = _small_cholesky(P2 + T2 + r2 - sol["q"])                                  # Psi (N, n, n), BI:115
+            logdet_psi = 2.0 * torch.log(torch.diagonal(Lp, dim1=1, dim2=2)).sum(dim=1)
+            mgl = nv * (nv - 1) / 4.0 * math.log(math.pi) + sum(torch.lgamma(nu / 2 - j / 2.0) for j in range(nv))
+            return (-0.5 * nv * M * math.log(2 * math.pi) + 0.5 * nv * sol["logdet"] - 0.5 * nu * nv * math.log(2.0) - mgl + logdet_psi * nu / 2)
         M = P0.numel()
         R0 = R1 = None
         r2 = r3 = 0.0
@@ -79,13 +90,18 @@ class Algorithm3(Algorithm1):
         new_int_var, new_basis = self._draw_int_vars(rand, time, new_state, suff_stats, a, factors)              # :139-148
         for i in range(self.N_int):
             new_int_var[i][-1] = ref_int_var[i]                                            # :149-152
-        new_stats = tuple(self.ops.stats_gather_update(1.0, a, suff_stats[i], new_basis[i], new_int_var[i].reshape(-1))
+        new_stats = tuple(self.ops.stats_gather_update(1.0, a, suff_stats[i], new_basis[i], new_int_var[i].reshape(-1) if self.nvar[i] == 1 else new_int_var[i])
                           for i in range(self.N_int))                                      # :155-162
         new_ref = []
         for i in range(self.N_int):                                                        # :165-176
             rb = self.basis_fcn[i](ref_state.reshape(1, -1), self._inp(time)).reshape(-1)
-            xi = ref_int_var[i].reshape(())
             R0, R1, R2, R3 = ref_suff_stats[i]
+            if self.nvar[i] > 1:
+                xi = ref_int_var[i].reshape(-1)
+                new_ref.append((R0.reshape(rb.numel(), -1) - rb[:, None] * xi[None, :], R1 - rb[:, None] * rb[None, :],
+                                R2.reshape(xi.numel(), xi.numel()) - xi[:, None] * xi[None, :], R3.reshape(()) - 1.0))
+                continue
+            xi = ref_int_var[i].reshape(())
             new_ref.append((R0.reshape(-1) - rb * xi, R1 - rb[:, None] * rb[None, :], R2.reshape(()) - xi * xi, R3.reshape(()) - 1.0))
         new_lw = self.SSM.log_likelihood(self._obs(time), new_state, self._inp(time), *new_int_var) - ll_aux[a.long()]   # :179-189
         return new_lw, new_state, new_int_var, new_stats, a, tuple(new_ref)
@@ -96,16 +112,21 @@ class Algorithm3(Algorithm1):
         state_trace, int_var_trace, _, lw_trace, anc_trace, suff_stats = self._init_algorithm(rand)
         T = self.observations.shape[0]
         ref_state = _t(ref_state.cpu() if isinstance(ref_state, torch.Tensor) else ref_state, dev).reshape(T, -1)
-        ref_int_var = [_t(v.cpu() if isinstance(v, torch.Tensor) else v, dev).reshape(T) for v in ref_int_var]
+        ref_int_var = [_t(v.cpu() if isinstance(v, torch.Tensor) else v, dev).reshape(T) if nv == 1 else
+                       _t(v.cpu() if isinstance(v, torch.Tensor) else v, dev).reshape(T, nv) for v, nv in zip(ref_int_var, self.nvar)]
         ref_ss = [[_t(r.cpu() if isinstance(r, torch.Tensor) else r, dev) for r in rs] for rs in ref_suff_stats]
-        ref_ss = [(r[0].reshape(-1), r[1], r[2].reshape(()), r[3].reshape(())) for r in ref_ss]
+        ref_ss = [(r[0].reshape(-1), r[1], r[2].reshape(()), r[3].reshape(())) if nv == 1 else
+                  (r[0].reshape(-1, nv), r[1], r[2].reshape(nv, nv), r[3].reshape(())) for r, nv in zip(ref_ss, self.nvar)]
         state_trace[0, -1] = ref_state[0]                                                  # :221
         suff_stats = [list(s) for s in suff_stats]
         for i in range(self.N_int):
             int_var_trace[i][0, -1] = ref_int_var[i][0]                                    # :224
             ib = self.basis_fcn[i](ref_state[:1], self.inputs[0]).reshape(-1)              # :225
             xi = ref_int_var[i][0]
-            iT = (ib * xi, ib[:, None] * ib[None, :], xi * xi, torch.ones((), dtype=torch.float64, device=dev))   # :226
+            if self.nvar[i] > 1:
+                iT = (ib[:, None] * xi[None, :], ib[:, None] * ib[None, :], xi[:, None] * xi[None, :], torch.ones((), dtype=torch.float64, device=dev))
+            else:
+                iT = (ib * xi, ib[:, None] * ib[None, :], xi * xi, torch.ones((), dtype=torch.float64, device=dev))   # :226
             for j in range(4):
                 suff_stats[i][j][-1] = iT[j]                                               # :228-231
             ref_ss[i] = tuple(ref_ss[i][j] - iT[j] for j in range(4))                      # :235-246

@@ -118,8 +118,13 @@ def test_algorithm1_with_a_two_component_interface_variable():
             assert tuple(got[5][0][j].shape) == np.shape(ref[5][0][j])
         _close(got[3], ref[3], "weights_trace")
         _close(got[7], ref[7], "log_likelihood", tol=1e-7)
-    with pytest.raises(NotImplementedError):
-        _device_alg(pb, N, "Algorithm3")
+
+
+def test_algorithm3_and_algorithm2_with_a_two_component_interface_variable():
+    """The conditional filter (general log base measure: n M, n log det eta1, multigammaln(nu / 2, n), log det Psi -- BI:111-124) and
+    the Particle-Gibbs chain over it, n = 2, against the NumPy restatement."""
+    _algorithm3_case(experiments.smo_two_component_marginal(T=8), 120)
+    _algorithm2_case(experiments.smo_two_component_marginal(T=7))
 
 
 @pytest.mark.parametrize("N,M", [(300, 41), (257, 62), (70, 14), (64, 1)])
@@ -347,9 +352,12 @@ def test_algorithm3_graph_replay_equals_eager_loop(name):
 def test_algorithm2_matches_restatement(name):
     """Whole Particle-Gibbs chains (Algorithm2 over Algorithm3): the device mirror splits its key once per iteration
     (pgas_amd.random.split); the restatement is given providers on those same per-iteration seeds."""
+    _algorithm2_case(_problem(name, T=7))
+
+
+def _algorithm2_case(pb):
     from pgas_amd import random as prng
 
-    pb = _problem(name, T=7)
     N, K = 96, 4
     ssm_t, ssm_n = pb.ssm(pgas_amd.StateSpaceModel, torch), pb.ssm(mo.StateSpaceModel, np)
     common = dict(N_samples=N, N_iterations=K, observations=pb.observations, inputs=pb.inputs, init_state_mean=pb.init_state_mean,
