@@ -46,6 +46,9 @@ class DeviceRand:
     def student_t(self, stream, t, nu):
         return self.ops.student_t(self.seed, stream, t, nu)
 
+    def student_t_df(self, stream, t, anc, src, nu0, nu_scale):
+        return self.ops.student_t_df(self.seed, stream, t, anc, src, nu0, nu_scale)
+
 
 def _small_cholesky(A):
     """Lower Cholesky factors of a batch (N, n, n) of small matrices in elementwise torch operations: no library call, no workspace, no
@@ -74,12 +77,17 @@ class Algorithm1:
         self.observations = _t(observations, dev)
         self.inputs = _t(inputs, dev)
         self.SSM = SSM
+        if hasattr(SSM, "bind"):   # SymbolicStateSpaceModel: its traced callables run through this object's device operations
+            SSM.bind(self.ops)
         self.forgetting_factor = float(forgetting_factor)
         self.init_state_mean = _t(init_state_mean, dev).reshape(-1)
         self.init_state_cov = np.atleast_2d(np.asarray(init_state_cov, dtype=np.float64))
         self.init_int_var_mean = [_t(m, dev).reshape(-1) for m in init_int_var_mean]
         self.init_int_var_cov = [np.atleast_2d(np.asarray(c, dtype=np.float64)) for c in init_int_var_cov]
         self.basis_fcn = list(basis_fcn)
+        for bf in self.basis_fcn:   # descriptors evaluate the whole batch in one HIP launch once they have the device operations
+            if hasattr(bf, "bind"):
+                bf.bind(self.ops)
         self.N_int = len(self.basis_fcn)
         self.dim_basis = [int(self.basis_fcn[i](self.init_state_mean.reshape(1, -1), self.inputs[0]).shape[-1]) for i in range(self.N_int)]  # :56-62
         self.GP_prior, self.nvar = [], []
@@ -201,6 +209,11 @@ class Algorithm1:
                 int_var.append(draw)
                 basis_all.append(basis)
                 continue
+            if hasattr(rand, "student_t_df"):   # device random numbers: degrees of freedom and the draw formed inside two kernels
+                t = rand.student_t_df(STREAM_INTVAR + i, time, a, T3, P3, scale)           # BI:45, :78, :104
+                int_var.append(self.ops.mniw_draw(scale, a, sol["m"], sol["c"], factors[i]["q"], T2, T3, P2, P3, t).unsqueeze(-1))   # BI:81-108
+                basis_all.append(basis)
+                continue
             df = P3 + scale * T3[ai]                                                       # BI:45; BI:78 with n = 1: df + 1 - 1
             row_scale = (P2 + scale * T2[ai] - factors[i]["q"][ai]) / df                   # BI:42, :87
             col_scale = sol["c"] + 1.0                                                     # BI:84
@@ -212,8 +225,10 @@ class Algorithm1:
 
     # ------------------------------------------------------------------------------------------------------ :275-295
     def _draw_states(self, rand, time, state, int_var, a):
-        ai = a.long()
         z = rand.normal(STREAM_STATE, time, state.shape[1])
+        if hasattr(self.SSM, "draw_state_gather"):   # the traced model gathers its parents' rows itself
+            return self.SSM.draw_state_gather(z, state, self._inp(time, 1), a, *int_var)
+        ai = a.long()
         return self.SSM.draw_state(z, state[ai], self._inp(time, 1), *[v[ai] for v in int_var])
 
     # ------------------------------------------------------------------------------------------------------ :297-397

@@ -24,14 +24,14 @@ from .Algorithm1 import Algorithm1  # noqa: F401
 from .Algorithm3 import Algorithm3  # noqa: F401
 from .Algorithm2 import Algorithm2  # noqa: F401
 from .PGAS import PGAS, condSequentialMonteCarlo  # noqa: F401
-from .StateSpaceModel import StateSpaceModel  # noqa: F401
+from .StateSpaceModel import StateSpaceModel, SymbolicStateSpaceModel  # noqa: F401
 
 __all__ = [
     "PGAS",
     "Algorithm1",
     "Algorithm2",
     "Algorithm3",
-    "StateSpaceModel",
+    "StateSpaceModel", "SymbolicStateSpaceModel",
     "condSequentialMonteCarlo",
     "generate_Hilbert_BasisFunction",
     "HilbertBasis",

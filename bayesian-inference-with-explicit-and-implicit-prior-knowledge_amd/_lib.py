@@ -41,7 +41,8 @@ EXPORTS = [
     "pgas_shard_setup", "pgas_shard_buffers", "pgas_shard_layout", "pgas_shard_block", "pgas_shard_set_peer_block", "pgas_shard_run", "pgas_ipc_export", "pgas_ipc_open",
     "pgas_hip_runtime_version", "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
     "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_student_t_host", "pgas_m_rng_chi2", "pgas_m_set_time_source", "pgas_m_rng_uniform_dev", "pgas_systematic_resample_dev", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
-    "pgas_m_mniw_solve_n", "pgas_m_mniw_trisolve_n", "pgas_m_stats_gather_update_n", "pgas_m_weighted_stats_n",
+    "pgas_m_mniw_solve_n", "pgas_m_mniw_trisolve_n", "pgas_m_stats_gather_update_n", "pgas_m_weighted_stats_n", "pgas_m_expr_eval",
+    "pgas_m_rng_student_t_df", "pgas_m_mniw_draw", "pgas_m_hilbert_basis",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)   # pgas_allgather_fn (include/pgas_hip.h)
@@ -167,6 +168,15 @@ def load():
     L.pgas_m_mniw_solve.argtypes = [vp, i64, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pgas_m_mniw_trisolve.restype = C.c_int
     L.pgas_m_mniw_trisolve.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp]
+    L.pgas_m_rng_student_t_df.restype = C.c_int
+    L.pgas_m_rng_student_t_df.argtypes = [vp, u64, C.c_uint32, C.c_uint32, i64, i64, vp, vp, C.c_double, C.c_double, vp, vp]
+    L.pgas_m_mniw_draw.restype = C.c_int
+    L.pgas_m_mniw_draw.argtypes = [vp, i64, C.c_double, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp]
+    L.pgas_m_hilbert_basis.restype = C.c_int
+    L.pgas_m_hilbert_basis.argtypes = [vp, i64, i32, i32, vp, i32, vp, i32, C.POINTER(i32), _dp, _dp, _dp, _dp, vp, vp, vp]
+    L.pgas_m_expr_eval.restype = C.c_int
+    L.pgas_m_expr_eval.argtypes = [vp, i64, vp, i32, vp, i32, i32, i32, C.POINTER(i32), i32, vp, i32, vp, vp, i32, C.POINTER(vp), C.POINTER(i32), i32, i32,
+                                   vp, vp, C.c_double, vp, vp]
     L.pgas_m_mniw_solve_n.restype = C.c_int
     L.pgas_m_mniw_solve_n.argtypes = [vp, i64, i32, i32, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.pgas_m_mniw_trisolve_n.restype = C.c_int
@@ -631,6 +641,43 @@ class MarginalOps:
                                                     self.eng._stream()), "pgas_m_rng_student_t")
         return out
 
+    def student_t_df(self, seed, stream, t, anc, src, nu0, nu_scale):
+        """Student-t variates with nu[p] = nu0 + nu_scale * src[anc[p]] formed inside the kernel."""
+        out = self._vec()
+        a = anc.to(device=self.device, dtype=torch.int32).contiguous()
+        self.eng._chk(self.lib.pgas_m_rng_student_t_df(self.eng._h, int(seed), int(stream), int(t), 0, self.N, a.data_ptr(), src.contiguous().data_ptr(),
+                                                       float(nu0), float(nu_scale), out.data_ptr(), self.eng._stream()), "pgas_m_rng_student_t_df")
+        return out
+
+    def mniw_draw(self, scale, anc, m, c, q, T2, T3, P2, P3, t):
+        """xi = m + sqrt((P2 + scale T2[a] - q[a]) / (P3 + scale T3[a])) t sqrt(c + 1) in one launch (pgas_m_mniw_draw)."""
+        n = m.shape[0]
+        out = self._vec(n)
+        a = anc.to(device=self.device, dtype=torch.int32).contiguous()
+        self.eng._chk(self.lib.pgas_m_mniw_draw(self.eng._h, n, float(scale), a.data_ptr(), m.contiguous().data_ptr(), c.contiguous().data_ptr(),
+                                                q.contiguous().data_ptr(), T2.contiguous().data_ptr(), T3.contiguous().data_ptr(), float(P2), float(P3),
+                                                t.contiguous().data_ptr(), out.data_ptr(), self.eng._stream()), "pgas_m_mniw_draw")
+        return out
+
+    def hilbert_basis(self, bmap, state, input=None):
+        """descriptors.BasisMap.batch for (n, n_x) states and one (n_u,) input in one launch (pgas_m_hilbert_basis) -> (n, M)."""
+        b = bmap.basis
+        n = state.shape[0]
+        state = state.reshape(n, -1).contiguous()
+        nx = state.shape[1]
+        inp = None if input is None or input.numel() == 0 else input.reshape(-1).contiguous()
+        nu = 0 if inp is None else inp.numel()
+        cache = bmap.__dict__.setdefault("_idx_dev", {})
+        if self.device not in cache:
+            cache[self.device] = torch.as_tensor(np.ascontiguousarray(b.indices, dtype=np.int32), device=self.device)
+        host = [np.ascontiguousarray(a, dtype=np.float64) for a in (bmap.div, b.center, b.L, b.size)]   # kept alive over the call
+        sel = np.ascontiguousarray(bmap.sel, dtype=np.int32)
+        out = torch.empty((n, b.M), dtype=torch.float64, device=self.device)
+        self.eng._chk(self.lib.pgas_m_hilbert_basis(self.eng._h, n, b.M, b.D, state.data_ptr(), nx, self._ptr(inp), nu, sel.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                    *[a.ctypes.data_as(_dp) for a in host], cache[self.device].data_ptr(), out.data_ptr(),
+                                                    self.eng._stream()), "pgas_m_hilbert_basis")
+        return out
+
     def mniw_solve(self, P0, P1, T0, T1, scale=1.0, anc=None, R0=None, R1=None, phi=None, want=("m", "c", "q", "logdet"), keep_factor=False):
         """eta0 = P0 + scale T0[anc] (+R0), eta1 = P1 + scale T1[anc] (+R1) per particle -> dict of (n,) tensors (see pgas_m_mniw_solve).
         keep_factor=True adds "L" (n, (M+2)(M+3)/2), the packed factor with the right-hand-side rows, for mniw_trisolve.
@@ -674,6 +721,35 @@ class MarginalOps:
         self.eng._chk(self.lib.pgas_m_mniw_trisolve_n(self.eng._h, n, M, max(nv, 1), self._ptr(a), fac["L"].data_ptr(), phi.contiguous().data_ptr(),
                                                       m.data_ptr(), c.data_ptr(), self.eng._stream()), "pgas_m_mniw_trisolve")
         return {"m": m, "c": c}
+
+    def expr_eval(self, prog, state, inp, ivs, mode=0, anc=None, aux=None, mat=None, cR=0.0):
+        """Run a traced model program (pgas_amd.exprs.Program) for every particle in one launch (pgas_m_expr_eval): mode 0 -> (n, n_out)
+        values, 1 -> values + aux @ mat.T (draw_state), 2 -> cR - |mat (aux - values)|^2 / 2 per particle (log_likelihood)."""
+        dev = self.device
+        cache = prog.__dict__.setdefault("_dev", {})
+        if dev not in cache:
+            cache[dev] = (torch.as_tensor(prog.code.reshape(-1), dtype=torch.int32, device=dev), torch.as_tensor(prog.consts, dtype=torch.float64, device=dev))
+        code_t, const_t = cache[dev]
+        nx, nu, ivw = prog.widths
+        n = state.shape[0]
+        state = state.reshape(n, nx).contiguous()
+        inp = inp.reshape(-1).contiguous() if nu else None
+        ivs = [v.reshape(n, w).contiguous() for v, w in zip(ivs, ivw)]
+        if state.dtype != torch.float64 or state.device != dev or len(ivs) != len(ivw) or (nu and inp.numel() != nu):
+            raise ValueError("expr_eval: operands do not match the traced program")
+        nout = len(prog.out_regs)
+        out = torch.empty((n,) if mode == 2 else (n, nout), dtype=torch.float64, device=dev)
+        a = None if anc is None else anc.to(device=dev, dtype=torch.int32).contiguous()
+        regs = (C.c_int32 * nout)(*prog.out_regs)
+        ptrs = (C.c_void_p * max(len(ivs), 1))(*[v.data_ptr() for v in ivs])
+        wid = (C.c_int32 * max(len(ivs), 1))(*ivw)
+        aux_c = None if aux is None else aux.reshape(-1).contiguous()
+        mat_c = None if mat is None else mat.contiguous()
+        self.eng._chk(self.lib.pgas_m_expr_eval(self.eng._h, n, code_t.data_ptr(), prog.code.shape[0], self._ptr(const_t) if prog.consts.size else None,
+                                                int(prog.consts.size), prog.n_in, prog.n_reg, regs, nout, state.data_ptr(), nx, self._ptr(a),
+                                                self._ptr(inp), nu, ptrs, wid, len(ivs), int(mode), self._ptr(aux_c), self._ptr(mat_c), float(cR),
+                                                out.data_ptr(), self.eng._stream()), "pgas_m_expr_eval")
+        return out
 
     def check(self):
         """Synchronises; raises if a matrix handed to mniw_solve since the last check was not positive definite."""

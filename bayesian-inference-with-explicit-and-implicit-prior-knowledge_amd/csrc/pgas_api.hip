@@ -1829,6 +1829,50 @@ int pgas_m_rng_student_t(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t
     return PGAS_OK;
 }
 
+/* Student-t variates whose degrees of freedom are formed in the kernel: nu[p] = nu0 + nu_scale * src[anc[p]] (df = P3 + lambda T3[a], BI:45). */
+int pgas_m_rng_student_t_df(pgas_ctx* c, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const int32_t* anc, const double* src, double nu0,
+                            double nu_scale, double* out, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!out || !src || !anc || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_rng_student_t_df: bad argument");
+    if (n == 0) return PGAS_OK;
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(k_rng_student_t, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, seed, stream, t, c->t_dev, p0, n, src, out, anc, nu0, nu_scale);
+    KCHK(c, "k_rng_student_t");
+    return PGAS_OK;
+}
+
+/* xi[p] = m[p] + sqrt((P2 + scale T2[a] - q[a]) / (P3 + scale T3[a])) t[p] sqrt(c[p] + 1), a = anc[p]: the scalar matrix-t draw (BI:64-108) */
+int pgas_m_mniw_draw(pgas_ctx* c, int64_t n, double scale, const int32_t* anc, const double* m, const double* cc, const double* q, const double* T2,
+                     const double* T3, double P2, double P3, const double* t, double* out, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!m || !cc || !q || !T2 || !T3 || !t || !out || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_mniw_draw: NULL argument");
+    if (n == 0) return PGAS_OK;
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(k_mniw_draw, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, n, scale, anc, m, cc, q, T2, T3, P2, P3, t, out);
+    KCHK(c, "k_mniw_draw");
+    return PGAS_OK;
+}
+
+/* phi (n, M) = the Hilbert basis at concat(state[p], input)[sel] / div for every particle (src/BasisFunctions.py:77-80): D <= 4 dimensions, the
+ * per-dimension tables on the host, the (M, D) index table on the device. */
+int pgas_m_hilbert_basis(pgas_ctx* c, int64_t n, int32_t M, int32_t D, const double* state, int32_t nx, const double* input, int32_t nu, const int32_t* sel,
+                         const double* div, const double* center, const double* L, const double* size, const int32_t* idx_dev, double* out, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!state || !sel || !div || !center || !L || !size || !idx_dev || !out || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_hilbert_basis: NULL argument");
+    if (D < 1 || D > PG_HB_MAXD || M < 1) FAIL(c, PGAS_E_ARG, "pgas_m_hilbert_basis: D = %d outside [1, %d]", D, PG_HB_MAXD);
+    HilbertArgs h{};
+    h.D = D; h.nx = nx; h.nu = nu;
+    for (int d = 0; d < D; ++d) {
+        if (sel[d] < 0 || sel[d] >= nx + nu || (sel[d] >= nx && !input)) FAIL(c, PGAS_E_ARG, "pgas_m_hilbert_basis: sel[%d] = %d outside the state / input", d, sel[d]);
+        h.sel[d] = sel[d]; h.div[d] = div[d]; h.center[d] = center[d]; h.L[d] = L[d]; h.size[d] = size[d]; h.amp[d] = std::sqrt(1.0 / L[d]);
+    }
+    if (n == 0) return PGAS_OK;
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(k_hilbert_batch, dim3((unsigned)((n * M + 255) / 256)), dim3(256), 0, (hipStream_t)sh, n, M, h, state, input, idx_dev, out);
+    KCHK(c, "k_hilbert_batch");
+    return PGAS_OK;
+}
+
 /* The same variates on the HOST (no context, no device): the library's own arithmetic (include/pgas_canon.h) compiled for the CPU, so
  * that host-side helpers (pgas_amd.prior_mniw_drawPred, BI:92-108) draw from the SAME streams as the kernels, bit for bit. */
 int pgas_m_rng_student_t_host(uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const double* nu_host, double* out_host) {
@@ -1915,6 +1959,33 @@ int pgas_m_mniw_trisolve_n(pgas_ctx* c, int64_t n, int32_t M, int32_t nv, const 
     hipLaunchKernelGGL(k_mniw_trisolve, dim3((unsigned)((n + waves - 1) / waves)), dim3(64 * waves),
                        (size_t)waves * ((M + 2) * (M + 3) / 2) * sizeof(double), (hipStream_t)sh, n, M, anc, Lfac, phi, m, cc);
     KCHK(c, "k_mniw_trisolve");
+    return PGAS_OK;
+}
+
+int pgas_m_expr_eval(pgas_ctx* c, int64_t n, const int32_t* code_dev, int32_t ninstr, const double* consts_dev, int32_t nconst, int32_t n_in, int32_t nreg,
+                     const int32_t* out_regs, int32_t nout, const double* state_dev, int32_t nx, const int32_t* anc_dev, const double* input_dev, int32_t nu,
+                     const double* const* iv_dev, const int32_t* iv_widths, int32_t n_iv, int32_t mode, const double* aux_dev, const double* mat_dev, double cR,
+                     double* out_dev, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!state_dev || !out_dev || !out_regs || (ninstr > 0 && !code_dev) || (nconst > 0 && !consts_dev) || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_expr_eval: NULL argument");
+    if (nreg < 1 || nreg > PG_EX_MAXREG || n_in + nconst > nreg) FAIL(c, PGAS_E_ARG, "pgas_m_expr_eval: %d registers outside [1, %d]", nreg, PG_EX_MAXREG);
+    if (nout < 1 || nout > PG_EX_MAXOUT || n_iv < 0 || n_iv > PG_EX_MAXIV || mode < 0 || mode > 2) FAIL(c, PGAS_E_ARG, "pgas_m_expr_eval: bad shape argument");
+    if ((nu > 0 && !input_dev) || (mode != 0 && (!aux_dev || !mat_dev))) FAIL(c, PGAS_E_ARG, "pgas_m_expr_eval: missing operand for this mode");
+    int w = nx + nu;
+    for (int i = 0; i < n_iv; ++i) w += iv_widths[i];
+    if (w != n_in) FAIL(c, PGAS_E_ARG, "pgas_m_expr_eval: the program expects %d inputs, the operands have %d", n_in, w);
+    for (int j = 0; j < nout; ++j)
+        if (out_regs[j] < 0 || out_regs[j] >= nreg) FAIL(c, PGAS_E_ARG, "pgas_m_expr_eval: output register out of range");
+    if (n == 0) return PGAS_OK;
+    DeviceGuard guard(c->device);
+    ExprArgs a{};
+    a.state = state_dev; a.anc = anc_dev; a.u = input_dev; a.n_iv = n_iv; a.nx = nx; a.nu = nu;
+    for (int i = 0; i < n_iv; ++i) { a.iv[i] = iv_dev[i]; a.ivw[i] = iv_widths[i]; }
+    a.code = code_dev; a.consts = consts_dev; a.ninstr = ninstr; a.nconst = nconst; a.n_in = n_in;
+    for (int j = 0; j < nout; ++j) a.out_reg[j] = out_regs[j];
+    a.nout = nout; a.mode = mode; a.aux = aux_dev; a.mat = mat_dev; a.cR = cR; a.out = out_dev;
+    hipLaunchKernelGGL(k_expr, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, n, a);
+    KCHK(c, "k_expr");
     return PGAS_OK;
 }
 

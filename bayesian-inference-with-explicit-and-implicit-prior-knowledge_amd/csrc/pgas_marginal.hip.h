@@ -25,12 +25,16 @@ __global__ __launch_bounds__(256) void k_rng_normal(uint64_t seed, uint32_t stre
     for (int k = 0; k < ncol; ++k) out[p * ncol + k] = z[k];
 }
 
+// nu_anc (nullable) / nu0 / nu_scale: degrees of freedom nu0 + nu_scale * nu[anc[p]] formed here (df = P3 + lambda T3[a], BI:45) instead of by two
+// torch launches in front of the kernel; the defaults (NULL, 0, 1) read nu[p] as before
 __global__ __launch_bounds__(256) void k_rng_student_t(uint64_t seed, uint32_t stream, uint32_t t, const uint32_t* __restrict__ t_dev, int64_t p0,
-                                                        int64_t n, const double* __restrict__ nu, double* __restrict__ out) {
+                                                        int64_t n, const double* __restrict__ nu, double* __restrict__ out,
+                                                        const int32_t* __restrict__ nu_anc = nullptr, double nu0 = 0.0, double nu_scale = 1.0) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
     if (t_dev) t = *t_dev;
-    out[p] = pgas_rng_student_t(seed, stream, t, (uint64_t)(p0 + p), nu[p]);
+    const double v = nu_anc ? nu0 + nu_scale * nu[nu_anc[p]] : nu[p];
+    out[p] = pgas_rng_student_t(seed, stream, t, (uint64_t)(p0 + p), v);
 }
 
 // chi^2(nu_p) = 2 Gamma(nu_p / 2): the Bartlett diagonal of PGAS.sample_params (src/PGAS.py:323-327), drawn where it is consumed
@@ -46,6 +50,7 @@ __global__ __launch_bounds__(256) void k_rng_chi2(uint64_t seed, uint32_t stream
     out[p] = 2.0 * pgas_rng_gamma(seed, stream, t, (uint64_t)(p0 + p), 0.5 * nu[p]);
 }
 
+#define PGAS_PI_D 3.141592653589793238462643383279502884
 #define PG_MN_MAXM 62      // one matrix row per lane plus the two right-hand-side rows; particles per workgroup = blockDim.x / 64
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -365,6 +370,120 @@ __global__ __launch_bounds__(256) void k_mniw_trisolve(int64_t n, int M, const i
     if (lane == 0) {
         if (m_out) m_out[p] = mm;
         if (c_out) c_out[p] = cc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_hilbert_batch: basis_fcn(state, input) for every particle (src/BasisFunctions.py:77-80 under the vmap of src/Algorithm1.py:220-225,
+// :243-248): phi[p][m] = prod_d amp_d sin(pi j[m][d] (v_d / div_d - center_d + L_d) / size_d), v = concat(state[p], input)[sel] -- one
+// launch instead of the ten elementwise launches of the torch expression.  Thread = (particle, function).
+// k_mniw_draw: the scalar matrix-t draw of src/Algorithm1.py:251-262 / BI:64-108 behind the stored-factor solve:
+//   xi = m + sqrt((P2 + s T2[a] - q[a]) / (P3 + s T3[a])) t sqrt(c + 1).
+// ------------------------------------------------------------------------------------------
+#define PG_HB_MAXD 4
+struct HilbertArgs {
+    int32_t D, nx, nu, sel[PG_HB_MAXD];
+    double div[PG_HB_MAXD], center[PG_HB_MAXD], L[PG_HB_MAXD], size[PG_HB_MAXD], amp[PG_HB_MAXD];
+};
+__global__ __launch_bounds__(256) void k_hilbert_batch(int64_t n, int M, HilbertArgs h, const double* __restrict__ state, const double* __restrict__ input,
+                                                        const int32_t* __restrict__ idx, double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * M) return;
+    const int64_t p = e / M;
+    const int m = (int)(e - p * M);
+    double prod = 1.0;
+    for (int d = 0; d < h.D; ++d) {
+        const int sd = h.sel[d];
+        const double v = sd < h.nx ? state[p * h.nx + sd] : input[sd - h.nx];
+        const double ang = PGAS_PI_D * (double)idx[m * h.D + d] * ((v / h.div[d] - h.center[d] + h.L[d]) / h.size[d]);
+        const double f = h.amp[d] * sin(ang);
+        prod = d == 0 ? f : prod * f;
+    }
+    out[e] = prod;
+}
+__global__ __launch_bounds__(256) void k_mniw_draw(int64_t n, double scale, const int32_t* __restrict__ anc, const double* __restrict__ m,
+                                                    const double* __restrict__ c, const double* __restrict__ q, const double* __restrict__ T2,
+                                                    const double* __restrict__ T3, double P2, double P3, const double* __restrict__ t,
+                                                    double* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int64_t a = anc ? (int64_t)anc[p] : p;
+    const double df = P3 + scale * T3[a];
+    const double row = (P2 + scale * T2[a] - q[a]) / df;
+    out[p] = m[p] + sqrt(row) * t[p] * sqrt(c[p] + 1.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_expr: a state-space model's transition / output function as DATA.  pgas_amd/exprs.py traces the model callable once into a register
+// program over per-particle scalars (opcode, destination, two sources; inputs and constants preloaded); this kernel runs it for every
+// particle in one launch -- an RK4 transition is ~20 instructions here and ~45 elementwise launches in torch (src/StateSpaceModel.py:32-87
+// evaluates the callables under jax.vmap).  Three tails share the program's result v (n_out values per particle):
+//   mode 0  out[p][k] = v_k                                                  transition_mdl / output_mdl          (:32-54)
+//   mode 1  out[p][k] = v_k + sum_l z[p][l] Qc[k][l]                         draw_state, z standard normals       (:56-74)
+//   mode 2  out[p]    = cR - 1/2 |LRinv (y - v)|^2                           log_likelihood                        (:76-87)
+// `anc` (nullable) gathers the state and the interface variables of particle anc[p] (the resampled parents, Algorithm1.py:350-353).
+// ------------------------------------------------------------------------------------------
+#define PG_EX_MAXREG 96
+#define PG_EX_MAXIV 4
+#define PG_EX_MAXOUT 8
+struct ExprArgs {
+    const double* state; const int32_t* anc; const double* u; const double* iv[PG_EX_MAXIV];
+    int32_t ivw[PG_EX_MAXIV], n_iv, nx, nu;
+    const int32_t* code; const double* consts; int32_t ninstr, nconst, n_in;
+    int32_t out_reg[PG_EX_MAXOUT], nout, mode;
+    const double* aux; const double* mat; double cR; double* out;
+};
+__global__ __launch_bounds__(256) void k_expr(int64_t n, ExprArgs a) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int64_t src = a.anc ? (int64_t)a.anc[p] : p;
+    double r[PG_EX_MAXREG];
+    int k = 0;
+    for (int j = 0; j < a.nx; ++j) r[k++] = a.state[src * a.nx + j];
+    for (int j = 0; j < a.nu; ++j) r[k++] = a.u[j];
+    for (int i = 0; i < a.n_iv; ++i)
+        for (int j = 0; j < a.ivw[i]; ++j) r[k++] = a.iv[i][src * a.ivw[i] + j];
+    for (int j = 0; j < a.nconst; ++j) r[a.n_in + j] = a.consts[j];
+    for (int i = 0; i < a.ninstr; ++i) {   // uniform control flow: every lane runs the same program
+        const int op = a.code[4 * i], d = a.code[4 * i + 1];
+        const double x = r[a.code[4 * i + 2]], y = r[a.code[4 * i + 3]];
+        double v;
+        switch (op) {
+            case 1: v = x + y; break;
+            case 2: v = x - y; break;
+            case 3: v = x * y; break;
+            case 4: v = x / y; break;
+            case 5: v = -x; break;
+            case 6: v = cos(x); break;
+            case 7: v = sin(x); break;
+            case 8: v = tan(x); break;
+            case 9: v = tanh(x); break;
+            case 10: v = atan(x); break;
+            case 11: v = sqrt(x); break;
+            case 12: v = exp(x); break;
+            case 13: v = (double)((x > 0.0) - (x < 0.0)); break;
+            default: v = x; break;
+        }
+        r[d] = v;
+    }
+    double val[PG_EX_MAXOUT];
+    for (int j = 0; j < a.nout; ++j) val[j] = r[a.out_reg[j]];
+    if (a.mode == 0) {
+        for (int j = 0; j < a.nout; ++j) a.out[p * a.nout + j] = val[j];
+    } else if (a.mode == 1) {
+        for (int j = 0; j < a.nout; ++j) {
+            double acc = val[j];
+            for (int l = 0; l < a.nout; ++l) acc += a.aux[p * a.nout + l] * a.mat[j * a.nout + l];
+            a.out[p * a.nout + j] = acc;
+        }
+    } else {
+        double q = 0.0;
+        for (int j = 0; j < a.nout; ++j) {
+            double e = 0.0;
+            for (int l = 0; l < a.nout; ++l) e += (a.aux[l] - val[l]) * a.mat[j * a.nout + l];
+            q += e * e;
+        }
+        a.out[p] = a.cR - 0.5 * q;
     }
 }
 

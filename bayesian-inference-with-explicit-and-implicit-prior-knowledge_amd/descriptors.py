@@ -69,6 +69,10 @@ class BasisMap:
             v = np.concatenate([v, np.atleast_1d(np.asarray(input, dtype=np.float64)).reshape(-1)])
         return self.basis(v[self.sel] / self.div)
 
+    def bind(self, ops):
+        """Algorithm1 / Algorithm3 hand over their device operations: batch() then runs as one HIP launch."""
+        self._ops = ops
+
     def trajectory(self, states, inputs=None):
         """Basis along a trajectory in one call: states (T, n_x), inputs (T, n_u) -- row t is evaluated with inputs[t] -> (T, M)."""
         return self.batch(states, inputs, per_row=True)
@@ -88,6 +92,9 @@ class BasisMap:
             return np.prod(np.sqrt(1.0 / b.L) * np.sin(ang), axis=2)
         import torch
 
+        ops = getattr(self, "_ops", None)
+        if ops is not None and not per_row and b.D <= 4 and state.dtype == torch.float64 and state.device == ops.device:
+            return ops.hilbert_basis(self, state, input)   # one HIP launch (pgas_m_hilbert_basis) instead of ten torch launches
         v = state.reshape(state.shape[0], -1)
         if input is not None and input.numel():
             rows = input.reshape(v.shape[0], -1) if per_row else input.reshape(1, -1).expand(v.shape[0], -1)

@@ -210,6 +210,10 @@ class MarginalProblem:
         f, g = self.model(xp)
         return cls(process_noise=self.process_noise, output_noise=self.output_noise, transition_model=f, output_model=g)
 
+    def ssm_symbolic(self, cls):
+        """The same model for pgas_amd.SymbolicStateSpaceModel: the factory itself, to be traced into one-launch programs."""
+        return cls(process_noise=self.process_noise, output_noise=self.output_noise, model=self.model)
+
     def basis_fcn(self):
         """basis_fcn[i](state (N,n_x), input) -> (N,M); entries of `basis` are BasisMap descriptors or plain batched callables."""
         return [_BatchedBasis(b) if hasattr(b, "batch") else b for b in self.basis]
@@ -311,6 +315,10 @@ class _BatchedBasis:
     def __call__(self, state, input):
         return self.b.batch(state, input)
 
+    def bind(self, ops):
+        if hasattr(self.b, "bind"):
+            self.b.bind(ops)
+
     def trajectory(self, states, inputs):
         return self.b.trajectory(states, inputs)
 
@@ -330,6 +338,9 @@ class _SlipAngleBasis:
 
     def batch(self, state, input):
         return self.map.batch(self.alpha(state, input).reshape(-1, 1), None)
+
+    def bind(self, ops):
+        self.map.bind(ops)
 
     def trajectory(self, states, inputs):
         return self.batch(states, inputs)

@@ -74,7 +74,7 @@ def bench_alg1(args, torch, dist, rank, local_rank, world):
 
     N, K, W = args.particles, args.steps, args.warmup
     pb = experiments.smo_marginal(T=K + W + 6)
-    ssm = pb.ssm(pgas_amd.StateSpaceModel, torch)
+    ssm = pb.ssm_symbolic(pgas_amd.SymbolicStateSpaceModel)   # the model callables traced into one-launch programs (StateSpaceModel + torch callables works the same)
     alg = pgas_amd.Algorithm1(N_samples=N, observations=pb.observations, inputs=pb.inputs, SSM=ssm, forgetting_factor=pb.forgetting_factor,
                               init_state_mean=pb.init_state_mean, init_state_cov=pb.init_state_cov, init_int_var_mean=pb.init_int_var_mean,
                               init_int_var_cov=pb.init_int_var_cov, GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn(), device=f"cuda:{local_rank}")

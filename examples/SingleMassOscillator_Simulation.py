@@ -29,7 +29,7 @@ def run(particles=200, iterations=800, steps=750, seed=12345678, device=None, lo
     from pgas_amd import random as prng
 
     pb = experiments.smo_marginal(T=steps, seed=seed)                     # src/SingleMassOscillator.py:14-139
-    ssm = pb.ssm(pgas_amd.StateSpaceModel, torch)
+    ssm = pb.ssm_symbolic(pgas_amd.SymbolicStateSpaceModel)   # the model callables traced into one-launch programs (StateSpaceModel + torch callables works the same)
     common = dict(observations=pb.observations, inputs=pb.inputs, SSM=ssm, init_state_mean=pb.init_state_mean, init_state_cov=pb.init_state_cov,
                   init_int_var_mean=pb.init_int_var_mean, init_int_var_cov=pb.init_int_var_cov, GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn(),
                   device=device)

@@ -20,7 +20,7 @@ def run_online_offline(pb, particles, iterations, seed=12345678, device=None, lo
     import pgas_amd
     from pgas_amd import random as prng
 
-    ssm = pb.ssm(pgas_amd.StateSpaceModel, torch)
+    ssm = pb.ssm_symbolic(pgas_amd.SymbolicStateSpaceModel)   # the model callables traced into one-launch programs (StateSpaceModel + torch callables works the same)
     common = dict(observations=pb.observations, inputs=pb.inputs, SSM=ssm, init_state_mean=pb.init_state_mean, init_state_cov=pb.init_state_cov,
                   init_int_var_mean=pb.init_int_var_mean, init_int_var_cov=pb.init_int_var_cov, GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn(),
                   device=device)

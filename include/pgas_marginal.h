@@ -81,6 +81,33 @@ int pgas_m_weighted_stats(pgas_ctx* ctx, int64_t n, int32_t M, const double* w_d
                           const double* T2_dev, const double* T3_dev, double* S0_dev, double* S1_dev, double* S2_dev, double* S3_dev,
                           void* stream_handle);
 
+/* Three small fusions of the filter step's per-particle glue (each replaces a handful of elementwise launches):
+ *   pgas_m_rng_student_t_df  Student-t variates with nu[p] = nu0 + nu_scale * src[anc[p]] formed in the kernel (df = P3 + lambda T3[a], BI:45);
+ *   pgas_m_mniw_draw         xi[p] = m[p] + sqrt((P2 + scale T2[a] - q[a]) / (P3 + scale T3[a])) t[p] sqrt(c[p] + 1), a = anc[p]  (BI:64-108, n = 1);
+ *   pgas_m_hilbert_basis     phi (n, M) = prod_d sqrt(1/L_d) sin(pi j[m][d] (v_d / div_d - center_d + L_d) / size_d), v = concat(state[p], input)[sel]
+ *                            (src/BasisFunctions.py:77-80 under the vmap of src/Algorithm1.py:220-225): sel / div / center / L / size host (D <= 4),
+ *                            idx_dev (M, D) int32 on the device. */
+int pgas_m_rng_student_t_df(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint32_t t, int64_t p0, int64_t n, const int32_t* anc_dev, const double* src_dev,
+                            double nu0, double nu_scale, double* out_dev, void* stream_handle);
+int pgas_m_mniw_draw(pgas_ctx* ctx, int64_t n, double scale, const int32_t* anc_dev, const double* m_dev, const double* c_dev, const double* q_dev,
+                     const double* T2_dev, const double* T3_dev, double P2, double P3, const double* t_dev, double* out_dev, void* stream_handle);
+int pgas_m_hilbert_basis(pgas_ctx* ctx, int64_t n, int32_t M, int32_t D, const double* state_dev, int32_t nx, const double* input_dev, int32_t nu,
+                         const int32_t* sel, const double* div, const double* center, const double* L, const double* size, const int32_t* idx_dev,
+                         double* out_dev, void* stream_handle);
+
+/* A model callable as data (src/StateSpaceModel.py:32-87: transition_mdl / output_mdl / draw_state / log_likelihood, which the reference
+ * evaluates per particle under jax.vmap): `code_dev` (ninstr, 4) int32 = (opcode, destination, source a, source b) over `nreg` <= 96 registers
+ * per particle; registers [0, n_in) are preloaded with the state's nx columns, the nu input components and the interface variables'
+ * components (in that order), [n_in, n_in + nconst) with `consts_dev`; opcodes 1..14 = add sub mul div neg cos sin tan tanh atan sqrt exp
+ * sign mov (pgas_amd/exprs.py traces a model written against an array namespace into this form).  The registers `out_regs` (host, nout <= 8)
+ * hold the result v; mode 0: out (n, nout) = v; mode 1: out = v + aux (n, nout) mat^T (draw_state: aux standard normals, mat = chol Q);
+ * mode 2: out (n) = cR - |mat (aux (nout) - v)|^2 / 2 (log_likelihood: aux = y_t, mat = chol(R)^-1).  anc_dev (nullable): particle p reads
+ * the state and interface variables of particle anc[p].  iv_dev / iv_widths: host arrays of n_iv <= 4 device pointers / widths. */
+int pgas_m_expr_eval(pgas_ctx* ctx, int64_t n, const int32_t* code_dev, int32_t ninstr, const double* consts_dev, int32_t nconst, int32_t n_in,
+                     int32_t nreg, const int32_t* out_regs, int32_t nout, const double* state_dev, int32_t nx, const int32_t* anc_dev,
+                     const double* input_dev, int32_t nu, const double* const* iv_dev, const int32_t* iv_widths, int32_t n_iv, int32_t mode,
+                     const double* aux_dev, const double* mat_dev, double cR, double* out_dev, void* stream_handle);
+
 /* The same four operations for an interface variable with nvar > 1 components (the reference's formulas are general in n: eta0 (M, n),
  * eta2 (n, n), BI:18-50, 53-61, 64-108; no configuration of the reference uses n > 1).  Layouts: P0 / R0 (M, nvar), T0 (n, M, nvar),
  * T2 (n, nvar, nvar), xi (n, nvar), all row-major; results m (n, nvar) = eta0^T eta1^-1 phi (BI:81), q (n, nvar, nvar) = eta0^T eta1^-1 eta0

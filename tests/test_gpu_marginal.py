@@ -297,6 +297,86 @@ def test_marginalised_filter_with_a_wide_basis():
     _close(got[3], ref[3], "weights_trace")
 
 
+def test_step_glue_kernels_against_torch():
+    """pgas_m_hilbert_basis, pgas_m_rng_student_t_df and pgas_m_mniw_draw against the torch expressions they replace."""
+    N = 900
+    ops = _ops(N)
+    dev = ops.device
+    g = torch.Generator(device="cpu").manual_seed(4)
+    for pb in (experiments.smo_marginal(T=4), experiments.emps_marginal(T=4), experiments.toy_marginal(T=4)):
+        bmap = pb.basis[0]
+        nx = pb.init_state_mean.shape[0]
+        st = (torch.randn(N, nx, generator=g, dtype=torch.float64) * 0.4).to(dev)
+        u = torch.as_tensor(np.asarray(pb.inputs, dtype=np.float64).reshape(pb.T, -1)[1], device=dev)
+        want = bmap.batch(st, u)                       # torch expression (nothing bound)
+        got = ops.hilbert_basis(bmap, st, u)
+        assert got.shape == want.shape and (got - want).abs().max().item() <= 1e-14 * max(1.0, want.abs().max().item())
+        ref = bmap.batch(st.cpu().numpy(), u.cpu().numpy())
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-13
+    anc = torch.randint(0, N, (N,), generator=g).to(dev).to(torch.int32)
+    T3 = (torch.rand(N, generator=g, dtype=torch.float64) * 40).to(dev)
+    t1 = ops.student_t_df(SEED, 32, 5, anc, T3, 3.0, 0.999)
+    t2 = ops.student_t(SEED, 32, 5, 3.0 + 0.999 * T3[anc.long()])
+    assert torch.equal(t1, t2)
+    m, c, q, T2 = [torch.rand(N, generator=g, dtype=torch.float64).to(dev) for _ in range(4)]
+    T2 = T2 + 2.0
+    got = ops.mniw_draw(0.999, anc, m, c, q, T2, T3, 1.5, 3.0, t1)
+    ai = anc.long()
+    want = m + torch.sqrt((1.5 + 0.999 * T2[ai] - q[ai]) / (3.0 + 0.999 * T3[ai])) * t1 * torch.sqrt(c + 1.0)
+    assert (got - want).abs().max().item() <= 1e-14 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["smo", "vehicle", "emps", "toy", "smo2"])
+def test_traced_model_programs_match_the_torch_callables(name):
+    """pgas_amd.SymbolicStateSpaceModel: transition / output / draw_state / log_likelihood as one launch each (pgas_m_expr_eval) against
+    the torch callables they were traced from, with and without an ancestor gather."""
+    pb = experiments.smo_two_component_marginal(T=6) if name == "smo2" else _problem(name, T=6)
+    N = 700
+    ops = _ops(N)
+    dev = ops.device
+    plain = pb.ssm(pgas_amd.StateSpaceModel, torch)
+    sym = pb.ssm_symbolic(pgas_amd.SymbolicStateSpaceModel)
+    sym.bind(ops)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    nx = pb.init_state_mean.shape[0]
+    st = (torch.randn(N, nx, generator=g, dtype=torch.float64) * 0.3).to(dev)
+    u = torch.as_tensor(np.asarray(pb.inputs, dtype=np.float64).reshape(pb.T, -1)[2], device=dev)
+    y = torch.as_tensor(np.asarray(pb.observations, dtype=np.float64).reshape(pb.T, -1)[2], device=dev)
+    ivs = [(torch.randn(N, np.asarray(m).reshape(-1).shape[0], generator=g, dtype=torch.float64) * 0.5).to(dev) for m in pb.init_int_var_mean]
+    z = torch.randn(N, nx, generator=g, dtype=torch.float64).to(dev)
+    anc = torch.randint(0, N, (N,), generator=g).to(dev).to(torch.int32)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")   # a model that falls back to torch would say so
+        pairs = [(sym.transition_mdl(st, u, *ivs), plain.transition_mdl(st, u, *ivs)),
+                 (sym.output_mdl(st, u, *ivs).reshape(N, -1), plain.output_mdl(st, u, *ivs).reshape(N, -1)),
+                 (sym.draw_state(z, st, u, *ivs), plain.draw_state(z, st, u, *ivs)),
+                 (sym.draw_state_gather(z, st, u, anc, *ivs), plain.draw_state(z, st[anc.long()], u, *[v[anc.long()] for v in ivs])),
+                 (sym.log_likelihood(y, st, u, *ivs), plain.log_likelihood(y, st, u, *ivs))]
+    for k, (a_, b_) in enumerate(pairs):
+        assert a_.shape == b_.shape, k
+        assert (a_ - b_).abs().max().item() <= 1e-12 * max(1.0, b_.abs().max().item()), k
+    assert all(p is not None for p in sym._progs.values()) and len(sym._progs) == 2, "both callables were traced"
+
+
+@pytest.mark.parametrize("name", ["smo", "vehicle"])
+def test_algorithm1_with_traced_model_matches_restatement(name):
+    """The filter with the model's callables running as traced programs: same results as with the torch callables (and the restatement)."""
+    N = 200
+    pb = _problem(name)
+    ref = marginal_oracle(pb, N)(CanonRand(SEED, N))
+    args = dict(N_samples=N, observations=pb.observations, inputs=pb.inputs, SSM=pb.ssm_symbolic(pgas_amd.SymbolicStateSpaceModel),
+                init_state_mean=pb.init_state_mean, init_state_cov=pb.init_state_cov, init_int_var_mean=pb.init_int_var_mean,
+                init_int_var_cov=pb.init_int_var_cov, GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn())
+    got = pgas_amd.Algorithm1(forgetting_factor=pb.forgetting_factor, **args)(SEED)
+    assert np.array_equal(got[4].cpu().numpy(), ref[4]), "ancestor_trace"
+    _close(got[0], ref[0], "state_trace")
+    for i in range(len(pb.basis)):
+        _close(got[1][i], ref[1][i], f"int_var_trace[{i}]")
+    _close(got[3], ref[3], "weights_trace")
+    _close(got[7], ref[7], "log_likelihood", tol=1e-7)
+
+
 def _flat(out):
     st, iv, sst, w, anc, stats, obs, ll = out
     return [st, w, anc, obs, ll] + list(iv) + [t for s in sst for t in s] + [t for s in stats for t in s]

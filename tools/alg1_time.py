@@ -6,7 +6,9 @@ import pgas_amd
 from pgas_amd import experiments
 N, T = 200, int(sys.argv[1]) if len(sys.argv) > 1 else 750
 pb = experiments.smo_marginal(T=T)
-ssm = pb.ssm(pgas_amd.StateSpaceModel, torch)
+# SYMBOLIC=1: the model's callables as traced one-launch programs (pgas_amd.SymbolicStateSpaceModel) instead of torch operations
+ssm = pb.ssm_symbolic(pgas_amd.SymbolicStateSpaceModel) if os.environ.get("SYMBOLIC") == "1" else pb.ssm(pgas_amd.StateSpaceModel, torch)
+print("model callables:", type(ssm).__name__, flush=True)
 alg = pgas_amd.Algorithm1(N_samples=N, observations=pb.observations, inputs=pb.inputs, SSM=ssm, forgetting_factor=pb.forgetting_factor,
                           init_state_mean=pb.init_state_mean, init_state_cov=pb.init_state_cov, init_int_var_mean=pb.init_int_var_mean,
                           init_int_var_cov=pb.init_int_var_cov, GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn())
