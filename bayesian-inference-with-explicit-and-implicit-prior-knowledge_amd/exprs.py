@@ -37,6 +37,7 @@ class Sym:
     """cols: node ids.  kind: "pp2" (N, k) per particle, "pp1" (N,) per particle, "u1" (k,) uniform vector, "u0" uniform scalar."""
 
     __array_priority__ = 1000
+    __array_ufunc__ = None   # numpy scalars (np.float64 constants of a model) defer to the reflected operators below
 
     def __init__(self, tr, cols, kind):
         self.tr, self.cols, self.kind = tr, list(cols), kind
