@@ -69,14 +69,24 @@ class Algorithm3(Algorithm1):
             # its index implementation-defined; here the reference particle keeps its own ancestor
             ref_idx = N - 1
         else:
-            g = torch.zeros(N, dtype=torch.float64, device=dev)
+            g = None
             for i in range(self.N_int):                                                    # :93-108  g_t - g_T
-                g = g + self._log_base_measure(i, suff_stats[i], sol=factors[i]) - self._log_base_measure(i, suff_stats[i], ref_suff_stats[i])
+                if self.nvar[i] == 1:   # both base measures and their difference in one launch, from the two solves' q / log det
+                    P0, P1, P2, P3 = self.GP_prior[i]
+                    T0, T1, T2, T3 = suff_stats[i]
+                    R0, R1, r2, r3 = ref_suff_stats[i]
+                    sol2 = self.ops.mniw_solve(P0, P1, T0, T1, R0=R0.reshape(-1).contiguous(), R1=R1.contiguous(), want=("q", "logdet"))
+                    gi = self.ops.lbm_diff(P0.numel(), T2, T3, factors[i], sol2, P2, P3, r2, r3)
+                else:
+                    gi = self._log_base_measure(i, suff_stats[i], sol=factors[i]) - self._log_base_measure(i, suff_stats[i], ref_suff_stats[i])
+                g = gi if g is None else g + gi
             if getattr(self, "_Qc", None) is None:
                 Lq = np.linalg.cholesky(self.SSM.process_noise)
                 self._Qc = (_t(np.linalg.inv(Lq), dev).T.contiguous(), -0.5 * Lq.shape[0] * math.log(2 * math.pi) - float(np.sum(np.log(np.diag(Lq)))))
-            e = (ref_state.reshape(1, -1) - aux_state) @ self._Qc[0]                       # :109-116
-            h_x = self._Qc[1] - 0.5 * (e * e).sum(dim=1)
+            h_x = self.SSM.transition_logpdf(ref_state, state, self._inp(time, 1), *int_var) if hasattr(self.SSM, "transition_logpdf") else None
+            if h_x is None:
+                e = (ref_state.reshape(1, -1) - aux_state) @ self._Qc[0]                   # :109-116
+                h_x = self._Qc[1] - 0.5 * (e * e).sum(dim=1)
             w_anc = torch.softmax(lw_aux + g + h_x, dim=0)                                 # :117-118
             u = rand.uniform_dev(STREAM_ANCESTOR, time) if graphed else torch.full((1,), rand.uniform(STREAM_ANCESTOR, time), dtype=torch.float64, device=dev)
             ref_idx = torch.clamp(torch.searchsorted(torch.cumsum(w_anc, 0), u)[0], max=N - 1)     # stays on the device: no host round trip

@@ -121,6 +121,19 @@ class SymbolicStateSpaceModel(StateSpaceModel):
             return self._ops.expr_eval(prog, state, u, int_variables, anc=anc)
         return self._ops.expr_eval(prog, state, u, int_variables, mode=1, anc=anc, aux=std_normal, mat=self._dev("Qc", self._Q_chol, state))
 
+    def transition_logpdf(self, target, state, input, *int_variables):
+        """log N(target; transition_model(state, input, ...), process_noise) per particle in one launch (src/Algorithm3.py:109-116), or None
+        when the transition is deterministic / not traced (the caller then uses its torch expression)."""
+        if self.is_deterministic:
+            return None
+        u = self._vec(input, state)
+        prog = self._program(0, state, u, int_variables)
+        if prog is None:
+            return None
+        Lq = self._Q_chol
+        cQ = -0.5 * Lq.shape[0] * math.log(2 * math.pi) - float(np.sum(np.log(np.diag(Lq))))
+        return self._ops.expr_eval(prog, state, u, int_variables, mode=2, aux=self._vec(target, state), mat=self._dev("LQinv", np.linalg.inv(Lq), state), cR=cQ)
+
     def log_likelihood(self, observation, state, input, *int_variables):
         u = self._vec(input, state)
         prog = self._program(1, state, u, int_variables)

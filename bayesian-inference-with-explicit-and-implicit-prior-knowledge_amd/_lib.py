@@ -42,7 +42,7 @@ EXPORTS = [
     "pgas_hip_runtime_version", "pgas_shard_unique_id", "pgas_shard_comm_init", "pgas_shard_sweep", "pgas_shard_set_collective", "pgas_get_launch_info", "pgas_shard_probe_collective", "pgas_detmath_eval",
     "pgas_m_rng_uniform", "pgas_m_rng_normal", "pgas_m_rng_student_t", "pgas_m_rng_student_t_host", "pgas_m_rng_chi2", "pgas_m_set_time_source", "pgas_m_rng_uniform_dev", "pgas_systematic_resample_dev", "pgas_m_mniw_solve", "pgas_m_mniw_trisolve", "pgas_m_check", "pgas_m_stats_gather_update", "pgas_m_weighted_stats",
     "pgas_m_mniw_solve_n", "pgas_m_mniw_trisolve_n", "pgas_m_stats_gather_update_n", "pgas_m_weighted_stats_n", "pgas_m_expr_eval",
-    "pgas_m_rng_student_t_df", "pgas_m_mniw_draw", "pgas_m_hilbert_basis",
+    "pgas_m_rng_student_t_df", "pgas_m_mniw_draw", "pgas_m_hilbert_basis", "pgas_m_lbm_diff",
 ]
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p)   # pgas_allgather_fn (include/pgas_hip.h)
@@ -172,6 +172,8 @@ def load():
     L.pgas_m_rng_student_t_df.argtypes = [vp, u64, C.c_uint32, C.c_uint32, i64, i64, vp, vp, C.c_double, C.c_double, vp, vp]
     L.pgas_m_mniw_draw.restype = C.c_int
     L.pgas_m_mniw_draw.argtypes = [vp, i64, C.c_double, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp]
+    L.pgas_m_lbm_diff.restype = C.c_int
+    L.pgas_m_lbm_diff.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp, vp]
     L.pgas_m_hilbert_basis.restype = C.c_int
     L.pgas_m_hilbert_basis.argtypes = [vp, i64, i32, i32, vp, i32, vp, i32, C.POINTER(i32), _dp, _dp, _dp, _dp, vp, vp, vp]
     L.pgas_m_expr_eval.restype = C.c_int
@@ -657,6 +659,16 @@ class MarginalOps:
         self.eng._chk(self.lib.pgas_m_mniw_draw(self.eng._h, n, float(scale), a.data_ptr(), m.contiguous().data_ptr(), c.contiguous().data_ptr(),
                                                 q.contiguous().data_ptr(), T2.contiguous().data_ptr(), T3.contiguous().data_ptr(), float(P2), float(P3),
                                                 t.contiguous().data_ptr(), out.data_ptr(), self.eng._stream()), "pgas_m_mniw_draw")
+        return out
+
+    def lbm_diff(self, M, T2, T3, sol1, sol2, P2, P3, r2, r3):
+        """lbm(prior + T) - lbm(prior + T + R) per particle from the two solves' q / logdet (pgas_m_lbm_diff; n = 1)."""
+        n = T2.shape[0]
+        out = self._vec(n)
+        r2, r3 = r2.reshape(-1).contiguous(), r3.reshape(-1).contiguous()
+        self.eng._chk(self.lib.pgas_m_lbm_diff(self.eng._h, n, int(M), T2.contiguous().data_ptr(), T3.contiguous().data_ptr(), sol1["q"].data_ptr(),
+                                               sol1["logdet"].data_ptr(), sol2["q"].data_ptr(), sol2["logdet"].data_ptr(), float(P2), float(P3),
+                                               r2.data_ptr(), r3.data_ptr(), out.data_ptr(), self.eng._stream()), "pgas_m_lbm_diff")
         return out
 
     def hilbert_basis(self, bmap, state, input=None):

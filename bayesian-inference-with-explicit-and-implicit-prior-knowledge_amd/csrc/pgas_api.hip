@@ -1853,6 +1853,18 @@ int pgas_m_mniw_draw(pgas_ctx* c, int64_t n, double scale, const int32_t* anc, c
     return PGAS_OK;
 }
 
+/* g[p] = lbm(prior + T[p]) - lbm(prior + T[p] + R): the ancestor weights' base-measure term (src/Algorithm3.py:93-108), n = 1; r2 / r3 on the device */
+int pgas_m_lbm_diff(pgas_ctx* c, int64_t n, int32_t M, const double* T2, const double* T3, const double* q1, const double* ld1, const double* q2,
+                    const double* ld2, double P2, double P3, const double* r2_dev, const double* r3_dev, double* out, void* sh) {
+    if (!c) return PGAS_E_ARG;
+    if (!T2 || !T3 || !q1 || !ld1 || !q2 || !ld2 || !r2_dev || !r3_dev || !out || n < 0) FAIL(c, PGAS_E_ARG, "pgas_m_lbm_diff: NULL argument");
+    if (n == 0) return PGAS_OK;
+    DeviceGuard guard(c->device);
+    hipLaunchKernelGGL(k_lbm_diff, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)sh, n, M, T2, T3, q1, ld1, q2, ld2, P2, P3, r2_dev, r3_dev, out);
+    KCHK(c, "k_lbm_diff");
+    return PGAS_OK;
+}
+
 /* phi (n, M) = the Hilbert basis at concat(state[p], input)[sel] / div for every particle (src/BasisFunctions.py:77-80): D <= 4 dimensions, the
  * per-dimension tables on the host, the (M, D) index table on the device. */
 int pgas_m_hilbert_basis(pgas_ctx* c, int64_t n, int32_t M, int32_t D, const double* state, int32_t nx, const double* input, int32_t nu, const int32_t* sel,

@@ -380,6 +380,22 @@ __global__ __launch_bounds__(256) void k_mniw_trisolve(int64_t n, int M, const i
 // k_mniw_draw: the scalar matrix-t draw of src/Algorithm1.py:251-262 / BI:64-108 behind the stored-factor solve:
 //   xi = m + sqrt((P2 + s T2[a] - q[a]) / (P3 + s T3[a])) t sqrt(c + 1).
 // ------------------------------------------------------------------------------------------
+// k_lbm_diff: g[p] = log base measure of (prior + statistics of particle p) minus that of (prior + statistics + the reference trajectory's
+// remaining statistics) -- the two vmap(BI.prior_mniw_log_base_measure) terms of the conditional filter's ancestor weights
+// (src/Algorithm3.py:93-108; BI:111-124 with n = 1: multigammaln(a, 1) = lgamma(a)) -- from the solves' q and log det:
+//   lbm(nu, Psi, logdet) = -M/2 log(2 pi) + logdet / 2 - nu / 2 log 2 - lgamma(nu / 2) + nu / 2 log Psi.
+__global__ __launch_bounds__(256) void k_lbm_diff(int64_t n, int M, const double* __restrict__ T2, const double* __restrict__ T3, const double* __restrict__ q1,
+                                                   const double* __restrict__ ld1, const double* __restrict__ q2, const double* __restrict__ ld2, double P2,
+                                                   double P3, const double* __restrict__ r2, const double* __restrict__ r3, double* __restrict__ out) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const double c0 = -0.5 * (double)M * 1.8378770664093454835606594728112353, ln2 = 0.6931471805599453094172321214581766;
+    const double nu1 = P3 + T3[p], psi1 = P2 + T2[p] - q1[p];
+    const double nu2 = P3 + T3[p] + r3[0], psi2 = P2 + T2[p] + r2[0] - q2[p];
+    const double a = c0 + 0.5 * ld1[p] - 0.5 * nu1 * ln2 - lgamma(nu1 / 2) + log(psi1) * nu1 / 2;
+    const double b = c0 + 0.5 * ld2[p] - 0.5 * nu2 * ln2 - lgamma(nu2 / 2) + log(psi2) * nu2 / 2;
+    out[p] = a - b;
+}
 #define PG_HB_MAXD 4
 struct HilbertArgs {
     int32_t D, nx, nu, sel[PG_HB_MAXD];

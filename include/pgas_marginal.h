@@ -91,6 +91,12 @@ int pgas_m_rng_student_t_df(pgas_ctx* ctx, uint64_t seed, uint32_t stream, uint3
                             double nu0, double nu_scale, double* out_dev, void* stream_handle);
 int pgas_m_mniw_draw(pgas_ctx* ctx, int64_t n, double scale, const int32_t* anc_dev, const double* m_dev, const double* c_dev, const double* q_dev,
                      const double* T2_dev, const double* T3_dev, double P2, double P3, const double* t_dev, double* out_dev, void* stream_handle);
+/* g[p] = lbm(P + T[p]) - lbm(P + T[p] + R) with lbm(nu, Psi, logdet) = -M/2 log 2pi + logdet/2 - nu/2 log 2 - lgamma(nu/2) + nu/2 log Psi: the
+ * base-measure term of the conditional filter's ancestor weights (src/Algorithm3.py:93-108, BI:111-124, n = 1) from the q / logdet of the two
+ * pgas_m_mniw_solve calls; r2_dev / r3_dev: the reference statistics' T2 / T3 (one double each, on the device). */
+int pgas_m_lbm_diff(pgas_ctx* ctx, int64_t n, int32_t M, const double* T2_dev, const double* T3_dev, const double* q1_dev, const double* logdet1_dev,
+                    const double* q2_dev, const double* logdet2_dev, double P2, double P3, const double* r2_dev, const double* r3_dev, double* out_dev,
+                    void* stream_handle);
 int pgas_m_hilbert_basis(pgas_ctx* ctx, int64_t n, int32_t M, int32_t D, const double* state_dev, int32_t nx, const double* input_dev, int32_t nu,
                          const int32_t* sel, const double* div, const double* center, const double* L, const double* size, const int32_t* idx_dev,
                          double* out_dev, void* stream_handle);
