@@ -326,6 +326,12 @@ class Algorithm1:
                     warnings.warn(f"the filter step could not be captured in a HIP graph ({type(e).__name__}: {e}); continuing without graph "
                                   "replay -- pass use_graph=False to skip the attempt", RuntimeWarning, stacklevel=3)
                     graph = None
+                    try:   # some failures (an operation HIP refuses inside a capture) invalidate the stream for good: say so instead of failing later, somewhere else
+                        torch.cuda.current_stream(dev).synchronize()
+                        (torch.zeros(1, device=dev) + 1).item()
+                    except Exception as e2:   # noqa: BLE001
+                        raise RuntimeError("the failed graph capture left the HIP stream unusable (" + type(e2).__name__ + "); this process cannot continue on "
+                                           "the device -- start again with use_graph=False") from e
                 for _ in range(3, T):                                      # the capture itself does not execute
                     if graph is not None:
                         graph.replay()
