@@ -500,3 +500,41 @@ def test_device_matches_committed_vectors(name):
     _close(gt.reshape(-1), np.array(g["alg3_state_traj"]), "Algorithm3 state trajectory")
     for i in range(len(pb.basis)):
         _close(gi[i].reshape(-1), np.array(g["alg3_int_var_traj"][i]), f"Algorithm3 int_var trajectory {i}")
+
+
+def test_a_model_that_cannot_be_captured_falls_back_or_says_why():
+    """A model callable that synchronises with the host cannot be captured in a HIP graph.  The filter either warns and goes on launch by
+    launch with the same results, or -- when the failed capture invalidated the stream -- raises an error that says so.  Run in a child
+    process: a poisoned stream must not reach the other tests."""
+    import os
+    import subprocess
+    import sys
+
+    code = r"""
+import sys, warnings
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import numpy as np, torch
+from common import experiments, pgas_amd
+pb = experiments.smo_marginal(T=8)
+def make(sync):
+    f, g = pb.model(torch)
+    def f_sync(state, input, *iv):
+        if sync:
+            float(state[0, 0].item())          # host round trip: not capturable
+        return f(state, input, *iv)
+    ssm = pgas_amd.StateSpaceModel(pb.process_noise, pb.output_noise, f_sync, g)
+    return pgas_amd.Algorithm1(N_samples=64, observations=pb.observations, inputs=pb.inputs, SSM=ssm, forgetting_factor=pb.forgetting_factor,
+                               init_state_mean=pb.init_state_mean, init_state_cov=pb.init_state_cov, init_int_var_mean=pb.init_int_var_mean,
+                               init_int_var_cov=pb.init_int_var_cov, GP_prior=pb.GP_prior, basis_fcn=pb.basis_fcn())
+ref = make(False)(7, use_graph=False)[0].cpu().numpy()
+with warnings.catch_warnings(record=True) as w:
+    warnings.simplefilter("always")
+    try:
+        got = make(True)(7, use_graph=True)[0].cpu().numpy()
+        print("WARNED" if any("could not be captured" in str(x.message) for x in w) else "SILENT", "EQUAL" if np.array_equal(got, ref) else "DIFFERENT")
+    except RuntimeError as e:
+        print("REFUSED" if "unusable" in str(e) else "OTHER " + str(e)[:200])
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    last = [ln for ln in out.stdout.splitlines() if ln.strip()][-1] if out.stdout.strip() else out.stderr[-400:]
+    assert last in ("WARNED EQUAL", "REFUSED"), (last, out.stderr[-600:])
